@@ -1,0 +1,177 @@
+/* viennaray_amd.h — C ABI of the MI355X-native flux ray-tracing core.
+ *
+ * This is the drop-in boundary for ONE path of ViennaTools/ViennaRay: the work
+ * done by Trace<T,D>::apply() (reference: include/viennaray/rayTrace.hpp:15-180,
+ * rayTraceDisk.hpp:19-57, rayTraceTriangle.hpp:19-61 and the ray loop in
+ * rayTraceKernel.hpp:32-426).  The reference has no FFI (header-only C++
+ * templates); the entry points below are what a `viennaray::TraceDisk` /
+ * `TraceTriangle` facade binds to (the headers under include/viennaray_amd/ are that facade,
+ * INTEGRATION.md shows the binding).  Everything is `extern "C"`, plain pointers
+ * and sizes; the library owns all HIP state.  NumericType on the device is
+ * float (Embree is float internally: rayUtil.hpp:96-97).
+ *
+ * Ownership: every host pointer is read during the call and never retained
+ * (the reference copies geometry into Embree buffers: rayGeometryDisk.hpp:123-176).
+ * Status: every function returning int returns VR_OK (0) or a negative VR_E_*;
+ * vr_last_error() gives the message.  HIP failures never abort the process.
+ * Threading: one context per host thread (the reference's Trace objects are not
+ * thread-safe either); a context binds one HIP device.
+ */
+#ifndef VIENNARAY_AMD_H
+#define VIENNARAY_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vr_context vr_context;
+
+enum {
+  VR_OK = 0,
+  VR_E_INVALID = -1,  /* bad argument / missing geometry or particle      */
+  VR_E_HIP = -2,      /* HIP runtime error (no device, OOM, launch failure) */
+  VR_E_STATE = -3     /* call order (e.g. get_flux before apply)           */
+};
+
+/* rayBoundary.hpp:10-14 */
+enum { VR_REFLECTIVE_BOUNDARY = 0, VR_PERIODIC_BOUNDARY = 1, VR_IGNORE_BOUNDARY = 2 };
+/* rayUtil.hpp:40-47 */
+enum { VR_POS_X = 0, VR_NEG_X = 1, VR_POS_Y = 2, VR_NEG_Y = 3, VR_POS_Z = 4, VR_NEG_Z = 5 };
+/* rayUtil.hpp:38 */
+enum { VR_NORM_SOURCE = 0, VR_NORM_MAX = 1 };
+/* built-in particle kinds (rayParticle.hpp:126-204) */
+enum { VR_PARTICLE_DIFFUSE = 0, VR_PARTICLE_SPECULAR = 1 };
+/* geometry kinds (rayGeometry.hpp:9) */
+enum { VR_GEOMETRY_DISK = 0, VR_GEOMETRY_TRIANGLE = 1 };
+
+/* rayUtil.hpp:65-76 (+ raysTerminated, a local of TraceKernel::apply) */
+typedef struct vr_trace_info {
+  uint64_t numRays;
+  uint64_t totalRaysTraced;
+  uint64_t nonGeometryHits;
+  uint64_t geometryHits;
+  uint64_t particleHits;
+  uint64_t boundaryHits;
+  uint64_t reflections;
+  uint64_t raysTerminated;
+  double time;          /* seconds: BVH build + ray loop, like the reference (Q10) */
+  double timeBuild;     /* seconds: BVH build part of `time`                       */
+  double timeTrace;     /* seconds: trace kernel only (HIP events)                 */
+  int32_t warning;
+  int32_t error;
+} vr_trace_info;
+
+/* gpu::Particle-style POD (rayParticle.hpp:208-218): a built-in particle.
+ * DIFFUSE ignores sourcePower (rayParticle.hpp:158 returns 1).             */
+typedef struct vr_particle {
+  int32_t kind;            /* VR_PARTICLE_*                                   */
+  float sticking;          /* stickingProbability_                            */
+  float sourcePower;       /* cosine exponent n of the source (SPECULAR only) */
+  int32_t numMaterialSticking;      /* 0 = none                               */
+  const int32_t *materialIds;       /* [numMaterialSticking] material id ...  */
+  const float *materialSticking;    /* ... -> sticking override               */
+} vr_particle;
+
+/* ---- life cycle (Trace::Trace / ~Trace, rayTrace.hpp:17-29) ------------- */
+int vr_create(vr_context **out, int device);
+void vr_destroy(vr_context *ctx);
+const char *vr_last_error(const vr_context *ctx);
+/* static: 1 if a HIP device is usable, 0 otherwise (never throws)           */
+int vr_device_available(void);
+const char *vr_version(void);
+
+/* ---- geometry ------------------------------------------------------------
+ * TraceDisk::setGeometry(points, normals, gridDelta[, diskRadius])
+ * (rayTraceDisk.hpp:62-92).  points/normals: n x 3 floats (for D==2 the z
+ * column is ignored, rayGeometryDisk.hpp:148-176).  diskRadius <= 0 selects
+ * gridDelta * DiskFactor<D> (rayUtil.hpp:99-101).                           */
+int vr_set_disks(vr_context *ctx, const float *points, const float *normals,
+                 uint32_t n, float gridDelta, float diskRadius, int D);
+/* TraceTriangle::setGeometry(TriangleMesh) (rayTraceTriangle.hpp:71-74;
+ * normals per rayMesh.hpp:99-112).  verts: nverts x 3, tris: ntris x 3.      */
+int vr_set_triangles(vr_context *ctx, const float *verts, uint32_t nverts,
+                     const uint32_t *tris, uint32_t ntris, float gridDelta, int D);
+/* setMaterialIds (rayGeometry.hpp:17-24)                                    */
+int vr_set_material_ids(vr_context *ctx, const int32_t *ids, uint32_t n);
+
+/* ---- configuration (rayTrace.hpp:41-121) -------------------------------- */
+int vr_set_boundary_conditions(vr_context *ctx, const int32_t *bcs, int n /* = D */);
+int vr_set_source_direction(vr_context *ctx, int traceDirection);
+int vr_set_primary_direction(vr_context *ctx, const float *dir3 /* NULL = off */);
+int vr_set_particle(vr_context *ctx, const vr_particle *particle);
+int vr_set_number_of_rays_per_point(vr_context *ctx, uint64_t n);
+int vr_set_number_of_rays_fixed(vr_context *ctx, uint64_t n);
+int vr_set_max_reflections(vr_context *ctx, uint32_t n);
+int vr_set_max_boundary_hits(vr_context *ctx, uint32_t n);
+int vr_set_rng_seed(vr_context *ctx, uint32_t seed);
+int vr_set_use_random_seeds(vr_context *ctx, int useRandom);
+/* KernelConfig::runNumber (rayUtil.hpp:93); apply() increments it           */
+int vr_set_run_number(vr_context *ctx, uint32_t runNumber);
+
+/* Multi-GPU sharding hook (not in the reference): trace only the global ray
+ * indices [first, first+count).  count == 0 restores "all rays".  Ray idx
+ * stays global, so the union over ranks reproduces the single-device stream
+ * (rayTraceKernel.hpp:118-121).                                             */
+int vr_set_ray_range(vr_context *ctx, uint64_t first, uint64_t count);
+
+/* ---- run (Trace::apply) -------------------------------------------------- */
+int vr_apply(vr_context *ctx);
+/* Same, split for benchmarking: build = bbox/boundary/areas/BVH/uploads,
+ * launch = zero accumulators + enqueue the trace kernel on the context's
+ * stream (asynchronous), finish = wait + read counters.                     */
+int vr_apply_prepare(vr_context *ctx);
+int vr_apply_launch(vr_context *ctx);
+int vr_apply_finish(vr_context *ctx);
+
+/* ---- results ------------------------------------------------------------- */
+uint32_t vr_num_primitives(const vr_context *ctx);
+/* getLocalData().getVectorData(0) (rayTrace.hpp:135): raw, un-normalised     */
+int vr_get_flux(vr_context *ctx, float *out, uint32_t n);
+int vr_get_flux_f64(vr_context *ctx, double *out, uint32_t n);
+int vr_get_trace_info(const vr_context *ctx, vr_trace_info *out);
+/* normalizeFlux / smoothFlux (rayTraceDisk.hpp:103-193, rayTraceTriangle.hpp:92-136),
+ * in place on a caller buffer                                               */
+int vr_normalize_flux(vr_context *ctx, float *flux, uint32_t n, int normType);
+int vr_smooth_flux(vr_context *ctx, float *flux, uint32_t n, int numNeighbors);
+/* geometry-derived values the reference exposes to its tests                */
+int vr_get_disk_areas(vr_context *ctx, float *out, uint32_t n);
+int vr_get_bounding_box(vr_context *ctx, float *out6 /* min xyz, max xyz, adjusted */);
+float vr_get_source_area(vr_context *ctx);
+float vr_get_disk_radius(const vr_context *ctx);
+int vr_get_neighbor_counts(vr_context *ctx, uint32_t *out, uint32_t n);
+
+/* ---- device accumulators for collectives (multi-GPU) ----------------------
+ * The per-primitive accumulator is an int64 fixed-point sum (weight * 2^VR_FLUX_FRAC_BITS),
+ * so sums are order-independent and an integer all-reduce is exact.  The
+ * pointer is DEVICE memory of `n` int64, in the caller's primitive order; it is
+ * valid after vr_apply_finish() until the next launch.  vr_flux_accumulators_from
+ * replaces the device contents (e.g. after an all-reduce done elsewhere).    */
+#define VR_FLUX_FRAC_BITS 40
+int vr_flux_accumulators(vr_context *ctx, void **devPtr, uint32_t *n);
+int vr_add_trace_info(vr_context *ctx, const vr_trace_info *other);
+/* stream the context launches on (hipStream_t as void*)                      */
+void *vr_stream(vr_context *ctx);
+
+/* ---- diagnostics used by the parity tests --------------------------------- */
+/* closest hit of explicit rays against {boundary, geometry} (rtcIntersect1 stand-in,
+ * rayTraceKernel.hpp:163-167).  geomID: 0 boundary, 1 geometry, -1 miss.     */
+int vr_debug_intersect(vr_context *ctx, const float *org, const float *dir,
+                       const float *tnear, uint32_t nrays, int32_t *geomID,
+                       uint32_t *primID, float *t);
+/* first (origin, direction) of global ray indices idx[] for kernel seed `seed`
+ * (raySourceRandom.hpp:25-36 after rayTraceKernel.hpp:120-121)               */
+int vr_debug_source_sample(vr_context *ctx, const uint64_t *idx, uint32_t n,
+                           uint32_t seed, float *org, float *dir);
+/* first `count` raw mt19937_64 outputs of the per-ray engine of ray idx      */
+int vr_debug_rng_outputs(vr_context *ctx, uint64_t idx, uint32_t seed,
+                         uint32_t count, uint64_t *out);
+/* BVH statistics: nodes, leaves, max depth */
+int vr_debug_bvh_stats(vr_context *ctx, uint32_t *out3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIENNARAY_AMD_H */

@@ -900,18 +900,23 @@ static bool intersect1(const Context &c, const Ray &ray, Hit &hit, float &tHit,
       bestPrim = p;
     }
   };
+  // Validity of each candidate is judged against the ray's own interval
+  // (tnear, FLT_MAX] — NOT against the shrinking tfar — so that the selected
+  // hit does not depend on the order primitives are visited in; `best` only
+  // prunes BVH subtrees.
+  const float TFAR = std::numeric_limits<float>::max();
   for (unsigned i = 0; i < 8; ++i) {
     float t;
-    if (intersectTri(ray, best, c.wall[i], t))
+    if (intersectTri(ray, TFAR, c.wall[i], t))
       consider(BOUNDARY_ID, i, t);
   }
   auto testPrim = [&](unsigned p) {
     float t;
     if (c.geoType == DISK) {
-      if (intersectDisc(ray, best, c.disks[p].data(), c.normals[p].data(), t))
+      if (intersectDisc(ray, TFAR, c.disks[p].data(), c.normals[p].data(), t))
         consider(GEOMETRY_ID, p, t);
     } else {
-      if (intersectTri(ray, best, c.triPre[p], t))
+      if (intersectTri(ray, TFAR, c.triPre[p], t))
         consider(GEOMETRY_ID, p, t);
     }
   };

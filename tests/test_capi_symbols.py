@@ -1,0 +1,49 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every
+symbol include/viennaray_amd.h declares, and fails loudly without a GPU."""
+import os
+import re
+
+import pytest
+
+import viennaray_amd as vr
+from viennaray_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "viennaray_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = vr.load()
+    names = _declared_symbols()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(L, n), f"missing export {n}"
+        assert n in capi.SIGNATURES, f"{n} has no ctypes signature"
+    assert set(capi.SIGNATURES) == set(names)
+
+
+def test_version_and_availability_do_not_need_a_gpu():
+    L = vr.load()
+    assert b"gfx950" in L.vr_version()
+    assert L.vr_device_available() in (0, 1)
+
+
+def test_no_cpu_fallback():
+    if vr.device_available():
+        pytest.skip("GPU present")
+    with pytest.raises(vr.VrError):
+        vr.TraceDisk(3)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "viennaray_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in src and "vr_oracle" not in src and "liboracle" not in src, f

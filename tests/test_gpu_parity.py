@@ -1,0 +1,325 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Integer work (RNG words, hit ids, counters, sticking-1
+flux) is bit-exact; float flux is compared by L2-relative error with the
+tolerance BASELINE.json's north_star states (1e-4)."""
+import numpy as np
+import pytest
+
+import viennaray_amd as vr
+from viennaray_amd import BoundaryCondition as BC, TraceDirection as TD
+from oracle import pyoracle as po
+from helpers import l2_rel, sphere3d, trench2d, trench3d, trench_mesh, DISK_FACTOR_3D
+
+pytestmark = pytest.mark.gpu
+
+FLUX_TOL = 1e-4  # north_star: "flux within 1e-4 relative of reference"
+INFO_KEYS = ("numRays", "totalRaysTraced", "nonGeometryHits", "geometryHits", "particleHits",
+             "boundaryHits", "reflections", "raysTerminated")
+
+
+def info_dict(t):
+    i = t.getRayTraceInfo()
+    return {k: int(getattr(i, k)) for k in INFO_KEYS}
+
+
+def make_pair_disks(pts, nrm, gd, D, bcs, direction, particle, rays_fixed=None, rays_pp=None, seed=12345,
+                    radius=0.0, primary=None):
+    t = vr.TraceDisk(D)
+    t.setGeometry(pts, nrm, gd, radius)
+    t.setBoundaryConditions(bcs)
+    t.setSourceDirection(direction)
+    o = po.Oracle()
+    o.set_disks(pts, nrm, gd, D, radius=radius)
+    o.set_boundary_conditions([int(b) for b in bcs])
+    o.set_source_direction(int(direction))
+    kind, sticking, power = particle
+    if kind == "diffuse":
+        t.setParticleType(vr.DiffuseParticle(sticking, "flux"))
+        o.set_particle(po.DIFFUSE, sticking)
+    else:
+        t.setParticleType(vr.SpecularParticle(sticking, power, "flux"))
+        o.set_particle(po.SPECULAR, sticking, power)
+    if rays_fixed:
+        t.setNumberOfRaysFixed(rays_fixed)
+        o.set_num_rays_fixed(rays_fixed)
+    else:
+        t.setNumberOfRaysPerPoint(rays_pp)
+        o.set_num_rays_per_point(rays_pp)
+    t.setRngSeed(seed)
+    o.set_rng_seed(seed)
+    if primary is not None:
+        t.setPrimaryDirection(primary)
+        o.set_primary_direction(primary)
+    o.set_lazy_rng(True)
+    return t, o
+
+
+def compare(t, o, exact_flux=False, counter_slack=0):
+    t.apply()
+    o.apply(po.max_threads())
+    f = t.getLocalData().getVectorData(0)
+    r = o.flux()
+    gi, oi = info_dict(t), o.info()
+    err = l2_rel(f, r)
+    for k in INFO_KEYS:
+        assert abs(gi[k] - oi[k]) <= counter_slack, (k, gi[k], oi[k], err)
+    if exact_flux and counter_slack == 0:
+        assert (f == r).all(), err
+    assert err <= FLUX_TOL, err
+    # SOURCE-normalised flux (BASELINE metric iii)
+    fn, rn = t.normalizeFlux(f), o.normalize_flux(r)
+    assert l2_rel(fn, rn) <= FLUX_TOL
+    return err, gi
+
+
+# ---------------------------------------------------------------------------
+def test_rng_stream_bit_exact():
+    t = vr.TraceDisk(3)
+    for idx, seed in ((0, 12346), (1, 12346), (123456789, 7), (2**32 - 1, 0xFFFFFFFF)):
+        got = t.debugRngOutputs(idx, seed, 700)  # tier 1, tier 2 and a second block twist
+        exp = po.mt64_outputs(po.tea3(idx, seed), 700)
+        assert (got == exp).all()
+
+
+def test_source_sample_matches_oracle():
+    gd, p, n = sphere3d()
+    for direction in (TD.POS_Z, TD.NEG_X, TD.POS_Y):
+        for power, primary in ((1.0, None), (50.0, None), (5.0, [0.2, 0.1, -1.0])):
+            t = vr.TraceDisk(3)
+            t.setGeometry(p, n, gd)
+            t.setSourceDirection(direction)
+            t.setParticleType(vr.SpecularParticle(1.0, power, "f"))
+            o = po.Oracle()
+            o.set_disks(p, n, gd, 3)
+            o.set_source_direction(int(direction))
+            o.set_particle(po.SPECULAR, 1.0, power)
+            if primary is not None:
+                # tilt relative to the tracing axis so the rejection loop is exercised
+                prim = np.roll(np.array(primary, dtype=np.float32), {TD.POS_Z: 0, TD.NEG_X: 1, TD.POS_Y: 2}[direction])
+                if direction == TD.NEG_X:
+                    prim[0] = abs(prim[0])
+                t.setPrimaryDirection(prim)
+                o.set_primary_direction(prim)
+            o.prepare()
+            idx = np.arange(4096, dtype=np.uint64)
+            org, d = t.debugSourceSample(idx, 31)
+            eo = np.empty_like(org)
+            ed = np.empty_like(d)
+            for i in range(idx.size):
+                eo[i], ed[i] = o.source_sample(int(idx[i]), 31)
+            assert (org == eo).all()  # origins: pure IEEE arithmetic -> bit exact
+            # directions go through sincosf/powf: the device evaluates them in
+            # double and rounds, glibc differs by <= 1 ulp in ~1 % of samples
+            ulp = np.abs(d.view(np.int32).astype(np.int64) - ed.view(np.int32).astype(np.int64))
+            small = (np.abs(d) < 1e-6) & (np.abs(ed) < 1e-6)  # around 0 ulps are meaningless
+            assert np.all((ulp <= 4) | small | (np.abs(d - ed) < 1e-7)), ulp.max()
+            assert (ulp > 0).mean() < 0.06
+
+
+def test_intersection_known_answers_gpu():
+    """tests/intersectionTest/intersectionTest.cpp:91-92,126-127 on the HIP path"""
+    r = np.float32(0.5 * DISK_FACTOR_3D)
+    pts, nrm = vr.io.create_plane_grid(0.5, 10)
+    t = vr.TraceDisk(3)
+    t.setGeometry(pts, nrm, 0.5, r)
+    t.setParticleType(vr.DiffuseParticle(1.0, "f"))
+    d = np.array([0, 2, -1.0])
+    d /= np.linalg.norm(d)
+    g, p, tt = t.debugIntersect([[0, 0, 2 * r], [0, 9, 2 * r]], [[0, 0, -1], d], tnear=0.0)
+    assert g[0] == 1 and p[0] == 840
+    assert g[1] == 0 and p[1] == 7
+
+
+@pytest.mark.parametrize("geom", ["sphere", "trench3d", "trench2d", "mesh"])
+def test_closest_hit_matches_oracle(geom):
+    rng = np.random.default_rng(5)
+    if geom == "mesh":
+        gd, v, tri = trench_mesh()
+        t = vr.TraceTriangle(3)
+        t.setGeometry(v, tri, gd)
+        o = po.Oracle()
+        o.set_triangles(v, tri, gd, 3)
+        lo, hi = v.min(0), v.max(0)
+        D = 3
+    else:
+        gd, p, n = {"sphere": sphere3d, "trench3d": trench3d, "trench2d": trench2d}[geom]()
+        D = 2 if geom == "trench2d" else 3
+        t = vr.TraceDisk(D)
+        t.setGeometry(p, n, gd)
+        o = po.Oracle()
+        o.set_disks(p, n, gd, D)
+        lo, hi = p.min(0), p.max(0)
+        if D == 2:
+            t.setSourceDirection(TD.POS_Y)
+            o.set_source_direction(po.POS_Y)
+    t.setParticleType(vr.DiffuseParticle(1.0, "f"))
+    o.prepare()
+    nr = 3000
+    org = rng.uniform(lo - 0.5, hi + 0.5, size=(nr, 3)).astype(np.float32)
+    d = rng.normal(size=(nr, 3))
+    if D == 2:
+        org[:, 2] = 0
+        d[:, 2] = 0
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    g, prim, tt = t.debugIntersect(org, d)
+    for i in range(nr):
+        h = o.intersect1(org[i], d[i])
+        assert g[i] == h["geomID"], i
+        if h["geomID"] >= 0:
+            assert prim[i] == h["primID"] and tt[i] == np.float32(h["t"]), (i, prim[i], h)
+
+
+# ---------------------------------------------------------------------------
+def test_rng_seed_config_bit_exact():
+    """tests/rngSeed/rngSeed.cpp geometry: 21x21 plane, sticking 1, 10 rays/point.
+    Integer weights -> the flux must equal the oracle's exactly, twice."""
+    pts, nrm = vr.io.create_plane_grid(0.5, 5)
+    t, o = make_pair_disks(pts, nrm, 0.5, 3, [BC.REFLECTIVE_BOUNDARY] * 3, TD.POS_Z, ("diffuse", 1.0, 1), rays_pp=10)
+    compare(t, o, exact_flux=True, counter_slack=2)
+    f1 = t.getLocalData().getVectorData(0).copy()
+    t2, _ = make_pair_disks(pts, nrm, 0.5, 3, [BC.REFLECTIVE_BOUNDARY] * 3, TD.POS_Z, ("diffuse", 1.0, 1), rays_pp=10)
+    t2.apply()
+    assert (t2.getLocalData().getVectorData(0) == f1).all()
+    assert t.getRayTraceInfo().numRays == 4410
+
+
+@pytest.mark.parametrize("bc", [BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY, BC.IGNORE_BOUNDARY])
+@pytest.mark.parametrize("sticking", [1.0, 0.1])
+def test_c1_plane_100x100(bc, sticking):
+    """BASELINE config C1 (P(100), 1e6 rays) on the HIP path vs the oracle."""
+    pts, nrm = vr.io.plane_grid(100, 1.0)
+    t, o = make_pair_disks(pts, nrm, 1.0, 3, [bc] * 3, TD.POS_Z, ("diffuse", sticking, 1), rays_fixed=1000000)
+    err, gi = compare(t, o, counter_slack=60)
+    print("C1", bc, sticking, "L2", err, gi)
+
+
+def test_trench3d_bounces():
+    """examples/disk3D geometry (28 919 disks), sticking 0.1: long bounce chains,
+    tier-2 RNG, back-face pass-through, roulette."""
+    gd, p, n = trench3d()
+    t, o = make_pair_disks(p, n, gd, 3, [BC.PERIODIC_BOUNDARY] * 3, TD.POS_Z, ("diffuse", 0.1, 1), rays_pp=20)
+    err, gi = compare(t, o, counter_slack=3000)
+    print("trench3d L2", err, gi)
+
+
+@pytest.mark.parametrize("bc", [BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY])
+def test_trench2d(bc):
+    """BASELINE config C5 geometry (239 disks, D=2, POS_Y)."""
+    gd, p, n = trench2d()
+    t, o = make_pair_disks(p, n, gd, 2, [bc, bc], TD.POS_Y, ("diffuse", 0.1, 1), rays_pp=2000)
+    err, gi = compare(t, o, counter_slack=3000)
+    print("trench2d", bc, "L2", err, gi)
+
+
+def test_trench2d_specular():
+    gd, p, n = trench2d()
+    t, o = make_pair_disks(p, n, gd, 2, [BC.REFLECTIVE_BOUNDARY] * 2, TD.POS_Y, ("specular", 0.2, 20.0), rays_pp=1000)
+    err, gi = compare(t, o, counter_slack=2000)
+    print("trench2d specular L2", err, gi)
+
+
+def test_sphere_all_directions():
+    gd, p, n = sphere3d()
+    for direction in TD:
+        t, o = make_pair_disks(p, n, gd, 3, [BC.REFLECTIVE_BOUNDARY] * 3, direction, ("diffuse", 0.3, 1), rays_pp=500)
+        err, gi = compare(t, o, counter_slack=400)
+
+
+def test_tilted_primary_direction():
+    pts, nrm = vr.io.plane_grid(40, 1.0)
+    t, o = make_pair_disks(pts, nrm, 1.0, 3, [BC.PERIODIC_BOUNDARY] * 3, TD.POS_Z, ("specular", 0.5, 30.0),
+                           rays_fixed=200000, primary=[0.3, 0.1, -1.0])
+    compare(t, o, counter_slack=40)
+
+
+def test_triangle_mesh_specular():
+    """BASELINE config C4 geometry: trenchMesh.dat, specular, power 50, reflective."""
+    gd, v, tri = trench_mesh()
+    t = vr.TraceTriangle(3)
+    t.setGeometry(v, tri, gd)
+    t.setParticleType(vr.SpecularParticle(0.1, 50.0, "flux"))
+    t.setNumberOfRaysPerPoint(40)
+    t.setRngSeed(12345)
+    o = po.Oracle()
+    o.set_triangles(v, tri, gd, 3)
+    o.set_particle(po.SPECULAR, 0.1, 50.0)
+    o.set_num_rays_per_point(40)
+    o.set_rng_seed(12345)
+    o.set_lazy_rng(True)
+    err, gi = compare(t, o, counter_slack=3000)
+    print("mesh specular L2", err, gi)
+
+
+def test_triangle_mesh_diffuse():
+    """examples/triangle3D: diffuse sticking 0.1."""
+    gd, v, tri = trench_mesh()
+    t = vr.TraceTriangle(3)
+    t.setGeometry(v, tri, gd)
+    t.setParticleType(vr.DiffuseParticle(0.1, "flux"))
+    t.setNumberOfRaysPerPoint(20)
+    t.setRngSeed(7)
+    o = po.Oracle()
+    o.set_triangles(v, tri, gd, 3)
+    o.set_particle(po.DIFFUSE, 0.1)
+    o.set_num_rays_per_point(20)
+    o.set_rng_seed(7)
+    o.set_lazy_rng(True)
+    err, gi = compare(t, o, counter_slack=3000)
+    print("mesh diffuse L2", err, gi)
+
+
+def test_ray_range_shards_sum_to_whole():
+    """Multi-GPU contract: tracing disjoint global ray-index ranges and adding the
+    integer accumulators reproduces the single-launch result exactly."""
+    pts, nrm = vr.io.plane_grid(64, 1.0)
+
+    def run(first, count):
+        t = vr.TraceDisk(3)
+        t.setGeometry(pts, nrm, 1.0)
+        t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+        t.setParticleType(vr.DiffuseParticle(0.3, "flux"))
+        t.setNumberOfRaysFixed(300000)
+        t.setRngSeed(99)
+        t.setRayRange(first, count)
+        t.apply()
+        return t.getFluxF64(), info_dict(t)
+
+    whole, wi = run(0, 0)
+    a, ai = run(0, 100000)
+    b, bi = run(100000, 120000)
+    c, ci = run(220000, 80000)
+    assert (a + b + c == whole).all()
+    for k in INFO_KEYS[1:]:
+        assert ai[k] + bi[k] + ci[k] == wi[k]
+
+
+def test_material_sticking_map():
+    pts, nrm = vr.io.plane_grid(32, 1.0)
+    mats = (np.arange(32 * 32) % 2).astype(np.int32)
+    t = vr.TraceDisk(3)
+    t.setGeometry(pts, nrm, 1.0)
+    t.setMaterialIds(mats)
+    t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+    t.setParticleType(vr.DiffuseParticle(1.0, "flux", materialSticking={1: 0.5}))
+    t.setNumberOfRaysFixed(100000)
+    t.setRngSeed(3)
+    t.apply()
+    i = info_dict(t)
+    # closest disk of material 1 -> the ray survives with weight 0.5 and reflects
+    assert 0.3 * 100000 < i["reflections"] < 0.7 * 100000
+
+
+def test_error_paths():
+    t = vr.TraceDisk(3)
+    with pytest.raises(vr.VrError):
+        t.apply()  # no particle
+    t.setParticleType(vr.DiffuseParticle(1.0, "f"))
+    with pytest.raises(vr.VrError):
+        t.apply()  # no geometry
+    pts, nrm = vr.io.plane_grid(8, 1.0)
+    t2 = vr.TraceDisk(2)
+    t2.setGeometry(pts, nrm, 1.0)
+    t2.setParticleType(vr.DiffuseParticle(1.0, "f"))
+    t2.setSourceDirection(TD.POS_Z)
+    with pytest.raises(vr.VrError):
+        t2.apply()  # 2-D with a z source

@@ -1,0 +1,781 @@
+// vr_api.cpp — the C ABI (include/viennaray_amd.h) on top of the host setup
+// (vr_host.cpp) and the HIP kernels (vr_trace.hip).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/viennaray_amd.h"
+#include "vr_host.hpp"
+#include "vr_kernels.hpp"
+#include "vr_types.hpp"
+
+using namespace vr;
+
+namespace {
+template <class T> struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap && p)
+      return hipSuccess;
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess)
+      cap = std::max<size_t>(n, 1);
+    return e;
+  }
+  void release() {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+} // namespace
+
+struct vr_context {
+  int device = 0;
+  int numCUs = 256;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+
+  HostGeometry geo;
+  bool geometryDirty = true; // BVH / uploads need rebuilding
+  Bvh bvh;
+  std::vector<uint32_t> leafOfOrig;
+  std::vector<float> diskAreas;
+
+  // Trace<T,D> configuration (rayTrace.hpp:157-179, rayUtil.hpp:83-94)
+  int bcs[3] = {0, 0, 0};
+  int sourceDirection = -1; // -1: default by D (POS_Y for 2-D, POS_Z for 3-D)
+  bool usePrimaryDirection = false;
+  float primaryDirection[3] = {0, 0, 0};
+  bool haveParticle = false;
+  int particleKind = 0;
+  float sticking = 1.f, sourcePower = 1.f;
+  std::vector<int32_t> matStickIds;
+  std::vector<float> matStickVals;
+  uint64_t numRaysPerPoint = 1000, numRaysFixed = 0;
+  uint32_t maxReflections = 0xFFFFFFFFu, maxBoundaryHits = 1000;
+  uint32_t rngSeed = 0;
+  bool useRandomSeed = true;
+  uint32_t runNumber = 1;
+  uint64_t rayFirst = 0, rayCount = 0;
+
+  // derived at prepare()
+  float bbLo[3], bbHi[3];
+  std::array<int, 5> ts{};
+  int boundaryConds[2] = {0, 0};
+  float sourceArea = 0.f;
+  uint64_t numRaysLast = 0;
+  bool prepared = false, launched = false, haveResult = false;
+  TraceParams params{};
+  unsigned grid = 0;
+
+  vr_trace_info info{};
+  double buildSeconds = 0.0;
+
+  // device buffers
+  DevBuf<float> dNodes, dPrims, dPrimSticking;
+  DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
+  DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
+  size_t scratchWaves = 0;
+};
+
+#define VR_HIP(ctx, call)                                                                                              \
+  do {                                                                                                                 \
+    hipError_t e__ = (call);                                                                                           \
+    if (e__ != hipSuccess) {                                                                                           \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                                                 \
+      return VR_E_HIP;                                                                                                 \
+    }                                                                                                                  \
+  } while (0)
+
+static int fail(vr_context *c, int code, const char *msg) {
+  if (c)
+    c->err = msg;
+  return code;
+}
+
+extern "C" {
+
+const char *vr_version(void) { return "viennaray_amd 0.1 (gfx950)"; }
+
+int vr_device_available(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  return (e == hipSuccess && n > 0) ? 1 : 0;
+}
+
+int vr_create(vr_context **out, int device) {
+  if (!out)
+    return VR_E_INVALID;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+    return VR_E_HIP;
+  vr_context *c = new vr_context();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return VR_E_HIP;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+    c->numCUs = prop.multiProcessorCount;
+  *out = c;
+  return VR_OK;
+}
+
+void vr_destroy(vr_context *c) {
+  if (!c)
+    return;
+  (void)hipSetDevice(c->device);
+  if (c->stream)
+    (void)hipStreamSynchronize(c->stream);
+  c->dNodes.release();
+  c->dPrims.release();
+  c->dPrimSticking.release();
+  c->dNbOff.release();
+  c->dNbIds.release();
+  c->dLeafOfOrig.release();
+  c->dFluxAcc.release();
+  c->dFluxOrig.release();
+  c->dCounters.release();
+  c->dScratch.release();
+  if (c->ev0)
+    (void)hipEventDestroy(c->ev0);
+  if (c->ev1)
+    (void)hipEventDestroy(c->ev1);
+  if (c->stream)
+    (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *vr_last_error(const vr_context *c) { return c ? c->err.c_str() : "null context"; }
+
+// ---- geometry ---------------------------------------------------------------
+int vr_set_disks(vr_context *c, const float *points, const float *normals, uint32_t n, float gridDelta,
+                 float diskRadius, int D) {
+  if (!c || !points || !normals || (D != 2 && D != 3) || n >= (1u << 27))
+    return fail(c, VR_E_INVALID, "vr_set_disks: bad argument");
+  host_set_disks(c->geo, points, normals, n, gridDelta, diskRadius, D);
+  c->geometryDirty = true;
+  c->prepared = c->haveResult = false;
+  return VR_OK;
+}
+
+int vr_set_triangles(vr_context *c, const float *verts, uint32_t nverts, const uint32_t *tris, uint32_t ntris,
+                     float gridDelta, int D) {
+  if (!c || !verts || !tris || (D != 2 && D != 3) || ntris >= (1u << 27))
+    return fail(c, VR_E_INVALID, "vr_set_triangles: bad argument");
+  for (size_t i = 0; i < (size_t)ntris * 3; ++i)
+    if (tris[i] >= nverts)
+      return fail(c, VR_E_INVALID, "vr_set_triangles: vertex index out of range");
+  host_set_triangles(c->geo, verts, nverts, tris, ntris, gridDelta, D);
+  c->geometryDirty = true;
+  c->prepared = c->haveResult = false;
+  return VR_OK;
+}
+
+int vr_set_material_ids(vr_context *c, const int32_t *ids, uint32_t n) {
+  if (!c || !ids)
+    return fail(c, VR_E_INVALID, "vr_set_material_ids: bad argument");
+  c->geo.materialIds.assign(ids, ids + n);
+  c->prepared = false;
+  return VR_OK;
+}
+
+// ---- configuration ----------------------------------------------------------
+int vr_set_boundary_conditions(vr_context *c, const int32_t *bcs, int n) {
+  if (!c || !bcs || n < 1 || n > 3)
+    return fail(c, VR_E_INVALID, "vr_set_boundary_conditions: bad argument");
+  for (int i = 0; i < n; ++i) {
+    if (bcs[i] < 0 || bcs[i] > 2)
+      return fail(c, VR_E_INVALID, "vr_set_boundary_conditions: unknown condition");
+    c->bcs[i] = bcs[i];
+  }
+  c->prepared = false;
+  return VR_OK;
+}
+int vr_set_source_direction(vr_context *c, int d) {
+  if (!c || d < 0 || d > 5)
+    return fail(c, VR_E_INVALID, "vr_set_source_direction: bad argument");
+  c->sourceDirection = d;
+  c->prepared = false;
+  return VR_OK;
+}
+int vr_set_primary_direction(vr_context *c, const float *d) {
+  if (!c)
+    return VR_E_INVALID;
+  if (d) {
+    std::memcpy(c->primaryDirection, d, 12);
+    c->usePrimaryDirection = true;
+  } else {
+    c->usePrimaryDirection = false;
+  }
+  c->prepared = false;
+  return VR_OK;
+}
+int vr_set_particle(vr_context *c, const vr_particle *p) {
+  if (!c || !p || (p->kind != VR_PARTICLE_DIFFUSE && p->kind != VR_PARTICLE_SPECULAR))
+    return fail(c, VR_E_INVALID, "vr_set_particle: bad argument");
+  c->particleKind = p->kind;
+  c->sticking = p->sticking;
+  // rayParticle.hpp:158,199
+  c->sourcePower = p->kind == VR_PARTICLE_DIFFUSE ? 1.f : p->sourcePower;
+  c->matStickIds.clear();
+  c->matStickVals.clear();
+  if (p->numMaterialSticking > 0 && p->materialIds && p->materialSticking) {
+    c->matStickIds.assign(p->materialIds, p->materialIds + p->numMaterialSticking);
+    c->matStickVals.assign(p->materialSticking, p->materialSticking + p->numMaterialSticking);
+  }
+  c->haveParticle = true;
+  c->prepared = false;
+  return VR_OK;
+}
+int vr_set_number_of_rays_per_point(vr_context *c, uint64_t n) {
+  if (!c)
+    return VR_E_INVALID;
+  c->numRaysPerPoint = n;
+  c->numRaysFixed = 0;
+  return VR_OK;
+}
+int vr_set_number_of_rays_fixed(vr_context *c, uint64_t n) {
+  if (!c)
+    return VR_E_INVALID;
+  c->numRaysFixed = n;
+  c->numRaysPerPoint = 0;
+  return VR_OK;
+}
+int vr_set_max_reflections(vr_context *c, uint32_t n) {
+  if (!c)
+    return VR_E_INVALID;
+  c->maxReflections = n;
+  return VR_OK;
+}
+int vr_set_max_boundary_hits(vr_context *c, uint32_t n) {
+  if (!c)
+    return VR_E_INVALID;
+  c->maxBoundaryHits = n;
+  return VR_OK;
+}
+int vr_set_rng_seed(vr_context *c, uint32_t s) {
+  if (!c)
+    return VR_E_INVALID;
+  c->rngSeed = s;
+  c->useRandomSeed = false;
+  return VR_OK;
+}
+int vr_set_use_random_seeds(vr_context *c, int b) {
+  if (!c)
+    return VR_E_INVALID;
+  c->useRandomSeed = b != 0;
+  return VR_OK;
+}
+int vr_set_run_number(vr_context *c, uint32_t r) {
+  if (!c)
+    return VR_E_INVALID;
+  c->runNumber = r;
+  return VR_OK;
+}
+int vr_set_ray_range(vr_context *c, uint64_t first, uint64_t count) {
+  if (!c)
+    return VR_E_INVALID;
+  c->rayFirst = first;
+  c->rayCount = count;
+  return VR_OK;
+}
+
+// ---- run ----------------------------------------------------------------------
+static int effective_direction(const vr_context *c) {
+  if (c->sourceDirection >= 0)
+    return c->sourceDirection;
+  return c->geo.D == 2 ? VR_POS_Y : VR_POS_Z; // rayTrace.hpp:166-167
+}
+
+int vr_apply_prepare(vr_context *c) {
+  if (!c)
+    return VR_E_INVALID;
+  VR_HIP(c, hipSetDevice(c->device));
+  c->info = vr_trace_info{};
+  // checkSettings (rayTraceDisk.hpp:196-217): the reference logs and carries
+  // on; with nothing to trace we stop and report through the error flag.
+  if (!c->haveParticle) {
+    c->info.error = 1;
+    return fail(c, VR_E_INVALID, "No particle was specified in rayTrace. Aborting.");
+  }
+  if (c->geo.numPrims == 0) {
+    c->info.error = 1;
+    return fail(c, VR_E_INVALID, "No geometry was passed to rayTrace. Aborting.");
+  }
+  const int D = c->geo.D;
+  const int dir = effective_direction(c);
+  if (D == 2 && (dir == VR_POS_Z || dir == VR_NEG_Z)) {
+    c->info.error = 1;
+    return fail(c, VR_E_INVALID, "Invalid source direction in 2D geometry. Aborting.");
+  }
+  if (c->geo.geo == 0 && c->geo.diskRadius > c->geo.gridDelta)
+    c->info.warning = 1;
+
+  const auto t0 = std::chrono::steady_clock::now();
+  // bounding box, trace settings, boundary (rayTraceDisk.hpp:21-27)
+  for (int k = 0; k < 3; ++k) {
+    c->bbLo[k] = c->geo.minC[k];
+    c->bbHi[k] = c->geo.maxC[k];
+  }
+  host_adjust_bbox(c->bbLo, c->bbHi, D, dir, c->geo.geo == 0 ? c->geo.diskRadius : c->geo.gridDelta);
+  c->ts = host_trace_settings(dir);
+  TraceParams &p = c->params;
+  host_build_walls(c->bbLo, c->bbHi, c->ts[1], c->ts[2], p.wall);
+  // rayBoundary.hpp:23-25: conditions are picked by AXIS
+  c->boundaryConds[0] = c->bcs[c->ts[1]];
+  c->boundaryConds[1] = (D == 2 && c->ts[2] >= 2) ? 0 : c->bcs[c->ts[2]];
+  if (c->geo.geo == 0)
+    host_disk_areas(c->geo, c->boundaryConds, c->ts[1], c->ts[2], c->diskAreas);
+  // SourceRandom::getSourceArea (raySourceRandom.hpp:40-47)
+  {
+    const int f = c->ts[1], s = c->ts[2];
+    c->sourceArea = D == 2 ? (c->bbHi[f] - c->bbLo[f]) : (c->bbHi[f] - c->bbLo[f]) * (c->bbHi[s] - c->bbLo[s]);
+  }
+
+  const uint32_t N = c->geo.numPrims;
+  if (c->geometryDirty) {
+    host_build_bvh(c->geo, c->bvh);
+    std::vector<float> prims;
+    host_pack_prims(c->geo, c->bvh, prims);
+    c->leafOfOrig.resize(N);
+    for (uint32_t q = 0; q < N; ++q)
+      c->leafOfOrig[c->bvh.order[q]] = q;
+    // neighbourhood CSR in leaf order
+    std::vector<uint32_t> off((size_t)N + 1, 0u), ids(c->geo.nbIds.size());
+    for (uint32_t q = 0; q < N; ++q) {
+      const uint32_t o = c->bvh.order[q];
+      off[q + 1] = off[q] + (c->geo.nbOff[o + 1] - c->geo.nbOff[o]);
+    }
+    for (uint32_t q = 0; q < N; ++q) {
+      const uint32_t o = c->bvh.order[q];
+      uint32_t w = off[q];
+      for (uint32_t j = c->geo.nbOff[o]; j < c->geo.nbOff[o + 1]; ++j)
+        ids[w++] = c->leafOfOrig[c->geo.nbIds[j]];
+    }
+    VR_HIP(c, c->dNodes.ensure(c->bvh.nodes.size()));
+    VR_HIP(c, c->dPrims.ensure(prims.size()));
+    VR_HIP(c, c->dNbOff.ensure(off.size()));
+    VR_HIP(c, c->dNbIds.ensure(ids.size()));
+    VR_HIP(c, c->dLeafOfOrig.ensure(N));
+    VR_HIP(c, c->dFluxAcc.ensure(N));
+    VR_HIP(c, c->dFluxOrig.ensure(N));
+    VR_HIP(c, c->dCounters.ensure(16));
+    VR_HIP(c, hipMemcpyAsync(c->dNodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dPrims.p, prims.data(), prims.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dNbOff.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!ids.empty())
+      VR_HIP(c, hipMemcpyAsync(c->dNbIds.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dLeafOfOrig.p, c->leafOfOrig.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    c->geometryDirty = false;
+  }
+  // per-primitive sticking from the material map (gpu::Particle-style, rayParticle.hpp:208-218)
+  const float *dStick = nullptr;
+  if (!c->matStickIds.empty()) {
+    std::vector<float> ps(N);
+    for (uint32_t q = 0; q < N; ++q) {
+      const uint32_t o = c->bvh.order[q];
+      const int mat = o < c->geo.materialIds.size() ? c->geo.materialIds[o] : 0;
+      float s = c->sticking;
+      for (size_t m = 0; m < c->matStickIds.size(); ++m)
+        if (c->matStickIds[m] == mat)
+          s = c->matStickVals[m];
+      ps[q] = s;
+    }
+    VR_HIP(c, c->dPrimSticking.ensure(N));
+    VR_HIP(c, hipMemcpy(c->dPrimSticking.p, ps.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+    dStick = c->dPrimSticking.p;
+  }
+
+  // launch geometry: enough blocks to fill the chip; the kernel is a work queue
+  c->grid = (unsigned)c->numCUs * 4u;
+  const size_t waves = (size_t)c->grid * (VR_BLOCK / 64);
+  if (waves > c->scratchWaves) {
+    VR_HIP(c, c->dScratch.ensure(waves * 312u * 64u));
+    c->scratchWaves = waves;
+  }
+
+  const uint64_t numRays = c->numRaysFixed == 0 ? (uint64_t)N * c->numRaysPerPoint : c->numRaysFixed;
+  c->numRaysLast = numRays;
+  uint64_t first = 0, last = numRays;
+  if (c->rayCount) {
+    first = std::min(c->rayFirst, numRays);
+    last = std::min(numRays, first + c->rayCount);
+  }
+  uint32_t seed = c->runNumber + c->rngSeed; // rayTraceKernel.hpp:100
+  if (c->useRandomSeed) {
+    std::random_device rd;
+    seed = (uint32_t)rd();
+  }
+  p.nodes = c->dNodes.p;
+  p.prims = c->dPrims.p;
+  p.nbOff = c->dNbOff.p;
+  p.nbIds = c->dNbIds.p;
+  p.primSticking = dStick;
+  p.fluxAcc = c->dFluxAcc.p;
+  p.counters = c->dCounters.p;
+  p.workCounter = c->dCounters.p + 8;
+  p.rngScratch = c->dScratch.p;
+  p.rayFirst = first;
+  p.rayEnd = last;
+  p.seed = seed;
+  p.numPrims = N;
+  p.maxReflections = c->maxReflections;
+  p.maxBoundaryHits = c->maxBoundaryHits;
+  {
+    const uint64_t span = last - first;
+    uint64_t chunk = 2048;
+    while (chunk > VR_BLOCK && span / chunk < (uint64_t)c->grid * 4)
+      chunk >>= 1;
+    p.chunk = (uint32_t)chunk;
+  }
+  p.rayDir = c->ts[0];
+  p.firstDir = c->ts[1];
+  p.secondDir = c->ts[2];
+  p.minMax = c->ts[3];
+  p.posNeg = (float)c->ts[4];
+  p.ee = 1.f / (c->sourcePower + 1); // raySourceRandom.hpp:21
+  p.sticking = c->sticking;
+  p.bc0 = c->boundaryConds[0];
+  p.bc1 = c->boundaryConds[1];
+  p.useBasis = c->usePrimaryDirection ? 1 : 0;
+  if (c->usePrimaryDirection)
+    host_orthonormal_basis(c->primaryDirection, p.basis);
+  else
+    std::memset(p.basis, 0, sizeof(p.basis));
+  for (int k = 0; k < 3; ++k) {
+    p.bbLo[k] = c->bbLo[k];
+    p.bbHi[k] = c->bbHi[k];
+  }
+  c->buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  c->prepared = true;
+  c->launched = false;
+  c->haveResult = false;
+  return VR_OK;
+}
+
+int vr_apply_launch(vr_context *c) {
+  if (!c)
+    return VR_E_INVALID;
+  if (!c->prepared)
+    return fail(c, VR_E_STATE, "vr_apply_launch: call vr_apply_prepare first");
+  VR_HIP(c, hipSetDevice(c->device));
+  const uint32_t N = c->geo.numPrims;
+  VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)N * 8, c->stream));
+  VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 16 * 8, c->stream));
+  VR_HIP(c, hipEventRecord(c->ev0, c->stream));
+  if (c->params.rayEnd > c->params.rayFirst)
+    VR_HIP(c, launch_trace(c->params, c->geo.D, c->geo.geo, c->particleKind, c->grid, c->stream));
+  VR_HIP(c, hipEventRecord(c->ev1, c->stream));
+  VR_HIP(c, launch_gather_flux(c->dFluxAcc.p, c->dLeafOfOrig.p, N, c->dFluxOrig.p, c->stream));
+  c->launched = true;
+  return VR_OK;
+}
+
+int vr_apply_finish(vr_context *c) {
+  if (!c)
+    return VR_E_INVALID;
+  if (!c->launched)
+    return fail(c, VR_E_STATE, "vr_apply_finish: nothing launched");
+  VR_HIP(c, hipSetDevice(c->device));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
+  unsigned long long cnt[8];
+  VR_HIP(c, hipMemcpy(cnt, c->dCounters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+  float ms = 0.f;
+  VR_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  vr_trace_info &i = c->info;
+  i.numRays = c->numRaysLast;
+  i.totalRaysTraced = cnt[C_TRACES];
+  i.nonGeometryHits = cnt[C_NONGEO];
+  i.geometryHits = cnt[C_GEO];
+  i.particleHits = cnt[C_PARTICLE];
+  i.boundaryHits = cnt[C_BOUNDARY];
+  i.reflections = cnt[C_REFLECTIONS];
+  i.raysTerminated = cnt[C_TERMINATED];
+  i.timeTrace = ms * 1e-3;
+  i.timeBuild = c->buildSeconds;
+  i.time = i.timeBuild + i.timeTrace;
+  ++c->runNumber; // rayTraceDisk.hpp:54
+  c->launched = false;
+  c->prepared = false;
+  c->haveResult = true;
+  return VR_OK;
+}
+
+int vr_apply(vr_context *c) {
+  int r = vr_apply_prepare(c);
+  if (r != VR_OK)
+    return r;
+  r = vr_apply_launch(c);
+  if (r != VR_OK)
+    return r;
+  return vr_apply_finish(c);
+}
+
+// ---- results --------------------------------------------------------------------
+uint32_t vr_num_primitives(const vr_context *c) { return c ? c->geo.numPrims : 0; }
+
+int vr_get_flux_f64(vr_context *c, double *out, uint32_t n) {
+  if (!c || !out)
+    return VR_E_INVALID;
+  if (!c->haveResult)
+    return fail(c, VR_E_STATE, "vr_get_flux: no result (call vr_apply)");
+  if (n != c->geo.numPrims)
+    return fail(c, VR_E_INVALID, "vr_get_flux: size mismatch");
+  VR_HIP(c, hipSetDevice(c->device));
+  std::vector<unsigned long long> acc(n);
+  VR_HIP(c, hipMemcpy(acc.data(), c->dFluxOrig.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  const double scale = std::ldexp(1.0, -VR_FLUX_FRAC_BITS);
+  for (uint32_t i = 0; i < n; ++i)
+    out[i] = (double)acc[i] * scale;
+  return VR_OK;
+}
+
+int vr_get_flux(vr_context *c, float *out, uint32_t n) {
+  if (!c || !out)
+    return VR_E_INVALID;
+  std::vector<double> tmp(n);
+  int r = vr_get_flux_f64(c, tmp.data(), n);
+  if (r != VR_OK)
+    return r;
+  for (uint32_t i = 0; i < n; ++i)
+    out[i] = (float)tmp[i];
+  return VR_OK;
+}
+
+int vr_get_trace_info(const vr_context *c, vr_trace_info *out) {
+  if (!c || !out)
+    return VR_E_INVALID;
+  *out = c->info;
+  return VR_OK;
+}
+
+int vr_add_trace_info(vr_context *c, const vr_trace_info *o) {
+  if (!c || !o)
+    return VR_E_INVALID;
+  vr_trace_info &i = c->info;
+  i.totalRaysTraced += o->totalRaysTraced;
+  i.nonGeometryHits += o->nonGeometryHits;
+  i.geometryHits += o->geometryHits;
+  i.particleHits += o->particleHits;
+  i.boundaryHits += o->boundaryHits;
+  i.reflections += o->reflections;
+  i.raysTerminated += o->raysTerminated;
+  return VR_OK;
+}
+
+int vr_flux_accumulators(vr_context *c, void **devPtr, uint32_t *n) {
+  if (!c || !devPtr)
+    return VR_E_INVALID;
+  if (!c->haveResult)
+    return fail(c, VR_E_STATE, "vr_flux_accumulators: no result");
+  *devPtr = c->dFluxOrig.p;
+  if (n)
+    *n = c->geo.numPrims;
+  return VR_OK;
+}
+
+void *vr_stream(vr_context *c) { return c ? (void *)c->stream : nullptr; }
+
+// rayTraceDisk.hpp:103-142, rayTraceTriangle.hpp:92-130
+int vr_normalize_flux(vr_context *c, float *flux, uint32_t n, int normType) {
+  if (!c || !flux || n != c->geo.numPrims)
+    return fail(c, VR_E_INVALID, "vr_normalize_flux: bad argument");
+  const bool disk = c->geo.geo == 0;
+  if (disk && c->diskAreas.size() != n)
+    return fail(c, VR_E_STATE, "vr_normalize_flux: call vr_apply first (disk areas)");
+  if (normType == VR_NORM_MAX) {
+    const float maxv = *std::max_element(flux, flux + n);
+    if (disk) {
+      const auto total = c->geo.diskRadius * c->geo.diskRadius * M_PI;
+      for (uint32_t i = 0; i < n; ++i)
+        flux[i] *= (total / c->diskAreas[i]) / maxv;
+    } else {
+      for (uint32_t i = 0; i < n; ++i)
+        flux[i] /= maxv * c->geo.triAreas[i];
+    }
+  } else {
+    if (c->numRaysLast == 0)
+      return fail(c, VR_E_STATE, "No source was specified in rayTrace for the normalization.");
+    const float normFactor = c->sourceArea / c->numRaysLast;
+    for (uint32_t i = 0; i < n; ++i)
+      flux[i] *= normFactor / (disk ? c->diskAreas[i] : c->geo.triAreas[i]);
+  }
+  return VR_OK;
+}
+
+// rayTraceDisk.hpp:146-193 (triangle version is a no-op: rayTraceTriangle.hpp:134-136)
+int vr_smooth_flux(vr_context *c, float *flux, uint32_t n, int numNeighbors) {
+  if (!c || !flux || n != c->geo.numPrims)
+    return fail(c, VR_E_INVALID, "vr_smooth_flux: bad argument");
+  if (c->geo.geo != 0 || numNeighbors < 1)
+    return VR_OK;
+  const std::vector<uint32_t> *off = &c->geo.nbOff, *ids = &c->geo.nbIds;
+  std::vector<uint32_t> woff, wids;
+  if (numNeighbors != 1) {
+    std::vector<float> pts((size_t)n * 3);
+    for (uint32_t i = 0; i < n; ++i)
+      std::memcpy(&pts[3 * (size_t)i], &c->geo.disk4[4 * (size_t)i], 12);
+    host_neighbors(c->geo.D, pts.data(), n, numNeighbors * 2 * c->geo.diskRadius, c->geo.minC, woff, wids);
+    off = &woff;
+    ids = &wids;
+  }
+  std::vector<float> old(flux, flux + n);
+  const float *nr = c->geo.normal3.data();
+  for (uint32_t i = 0; i < n; ++i) {
+    float vv = old[i];
+    float sum = 1.f;
+    for (uint32_t j = (*off)[i]; j < (*off)[i + 1]; ++j) {
+      const uint32_t nb = (*ids)[j];
+      const float w = (nr[3 * (size_t)i] * nr[3 * (size_t)nb] + nr[3 * (size_t)i + 1] * nr[3 * (size_t)nb + 1]) +
+                      nr[3 * (size_t)i + 2] * nr[3 * (size_t)nb + 2];
+      if (w > 0.f) {
+        vv += old[nb] * w;
+        sum += w;
+      }
+    }
+    flux[i] = vv / sum;
+  }
+  return VR_OK;
+}
+
+int vr_get_disk_areas(vr_context *c, float *out, uint32_t n) {
+  if (!c || !out || n != c->geo.numPrims || c->diskAreas.size() != n)
+    return fail(c, VR_E_STATE, "vr_get_disk_areas: not available");
+  std::memcpy(out, c->diskAreas.data(), (size_t)n * 4);
+  return VR_OK;
+}
+int vr_get_bounding_box(vr_context *c, float *out6) {
+  if (!c || !out6)
+    return VR_E_INVALID;
+  for (int k = 0; k < 3; ++k) {
+    out6[k] = c->bbLo[k];
+    out6[k + 3] = c->bbHi[k];
+  }
+  return VR_OK;
+}
+float vr_get_source_area(vr_context *c) { return c ? c->sourceArea : 0.f; }
+float vr_get_disk_radius(const vr_context *c) { return c ? c->geo.diskRadius : 0.f; }
+int vr_get_neighbor_counts(vr_context *c, uint32_t *out, uint32_t n) {
+  if (!c || !out || n != c->geo.numPrims)
+    return VR_E_INVALID;
+  for (uint32_t i = 0; i < n; ++i)
+    out[i] = c->geo.nbOff[i + 1] - c->geo.nbOff[i];
+  return VR_OK;
+}
+
+// ---- diagnostics ------------------------------------------------------------------
+int vr_debug_intersect(vr_context *c, const float *org, const float *dir, const float *tnear, uint32_t n,
+                       int32_t *geomID, uint32_t *primID, float *t) {
+  if (!c || !org || !dir || !tnear || !geomID || !primID || !t)
+    return VR_E_INVALID;
+  if (!c->prepared) {
+    int r = vr_apply_prepare(c);
+    if (r != VR_OK)
+      return r;
+  }
+  DevBuf<float> dO, dD, dT, dt;
+  DevBuf<int> dG;
+  DevBuf<uint32_t> dP;
+  VR_HIP(c, dO.ensure((size_t)n * 3));
+  VR_HIP(c, dD.ensure((size_t)n * 3));
+  VR_HIP(c, dT.ensure(n));
+  VR_HIP(c, dt.ensure(n));
+  VR_HIP(c, dG.ensure(n));
+  VR_HIP(c, dP.ensure(n));
+  VR_HIP(c, hipMemcpy(dO.p, org, (size_t)n * 12, hipMemcpyHostToDevice));
+  VR_HIP(c, hipMemcpy(dD.p, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+  VR_HIP(c, hipMemcpy(dT.p, tnear, (size_t)n * 4, hipMemcpyHostToDevice));
+  VR_HIP(c, launch_debug_intersect(c->params, c->geo.geo, dO.p, dD.p, dT.p, n, dG.p, dP.p, dt.p, c->stream));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
+  VR_HIP(c, hipMemcpy(geomID, dG.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  VR_HIP(c, hipMemcpy(primID, dP.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  VR_HIP(c, hipMemcpy(t, dt.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  dO.release();
+  dD.release();
+  dT.release();
+  dt.release();
+  dG.release();
+  dP.release();
+  return VR_OK;
+}
+
+int vr_debug_source_sample(vr_context *c, const uint64_t *idx, uint32_t n, uint32_t seed, float *org, float *dir) {
+  if (!c || !idx || !org || !dir)
+    return VR_E_INVALID;
+  if (!c->prepared) {
+    int r = vr_apply_prepare(c);
+    if (r != VR_OK)
+      return r;
+  }
+  if ((size_t)((n + 63) / 64) > c->scratchWaves)
+    return fail(c, VR_E_INVALID, "vr_debug_source_sample: too many rays for one call");
+  TraceParams p = c->params;
+  p.seed = seed;
+  DevBuf<unsigned long long> dI;
+  DevBuf<float> dO, dD;
+  VR_HIP(c, dI.ensure(n));
+  VR_HIP(c, dO.ensure((size_t)n * 3));
+  VR_HIP(c, dD.ensure((size_t)n * 3));
+  VR_HIP(c, hipMemcpy(dI.p, idx, (size_t)n * 8, hipMemcpyHostToDevice));
+  VR_HIP(c, launch_debug_source(p, c->geo.D, dI.p, n, dO.p, dD.p, c->stream));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
+  VR_HIP(c, hipMemcpy(org, dO.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+  VR_HIP(c, hipMemcpy(dir, dD.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+  dI.release();
+  dO.release();
+  dD.release();
+  return VR_OK;
+}
+
+int vr_debug_rng_outputs(vr_context *c, uint64_t idx, uint32_t seed, uint32_t count, uint64_t *out) {
+  if (!c || !out)
+    return VR_E_INVALID;
+  VR_HIP(c, hipSetDevice(c->device));
+  // tea<3>(idx, seed) on the host (same mix as vr_device.hpp)
+  unsigned v0 = (unsigned)idx, v1 = seed, s0 = 0;
+  for (int n = 0; n < 3; ++n) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+  }
+  DevBuf<unsigned long long> dS, dOut;
+  VR_HIP(c, dS.ensure(312u * 64u));
+  VR_HIP(c, dOut.ensure(count));
+  VR_HIP(c, launch_debug_rng(v0, count, dS.p, dOut.p, c->stream));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
+  VR_HIP(c, hipMemcpy(out, dOut.p, (size_t)count * 8, hipMemcpyDeviceToHost));
+  dS.release();
+  dOut.release();
+  return VR_OK;
+}
+
+int vr_debug_bvh_stats(vr_context *c, uint32_t *out3) {
+  if (!c || !out3)
+    return VR_E_INVALID;
+  out3[0] = c->bvh.numNodes;
+  out3[1] = c->bvh.numLeaves;
+  out3[2] = c->bvh.maxDepth;
+  return VR_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,362 @@
+// vr_device.hpp — device-side building blocks of the flux tracer (gfx950).
+//
+// Everything here is compiled with -ffp-contract=off: the order of float
+// operations is part of the parity contract with the reference semantics
+// (see DESIGN.md §Numerics); fused multiply-adds are written explicitly where
+// they are wanted (BVH slab test only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vr_types.hpp"
+
+namespace vr {
+
+struct V3 {
+  float x, y, z;
+};
+
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ float getc(const V3 &v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+__device__ __forceinline__ void setc(V3 &v, int a, float f) {
+  v.x = a == 0 ? f : v.x;
+  v.y = a == 1 ? f : v.y;
+  v.z = a == 2 ? f : v.z;
+}
+// ViennaCore DotProduct: sequential accumulation starting from 0
+__device__ __forceinline__ float vdot(const V3 &a, const V3 &b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// Embree SSE2 dot: x + (y + z)
+__device__ __forceinline__ float edot(const V3 &a, const V3 &b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ V3 ecross(const V3 &a, const V3 &b) {
+  return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 vsub(const V3 &a, const V3 &b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ void vnormalize(V3 &a) {
+  float n = sqrtf(vdot(a, a));
+  if (n <= 0.f)
+    return;
+  a.x /= n;
+  a.y /= n;
+  a.z /= n;
+}
+
+// ---------------------------------------------------------------------------
+// Per-ray RNG: mt19937_64 seeded with tea<3>(idx, seed)
+// (reference: rayTraceKernel.hpp:100,120-121; engine = std::mt19937_64).
+//
+// A fresh 312-word engine per ray is what makes the reference's CPU loop
+// expensive; on the GPU the stream is evaluated lazily from its recurrence
+//   s[0] = seed, s[j] = 6364136223846793005 (s[j-1] ^ s[j-1]>>62) + j  (j < 312)
+//   s[n+312] = s[n+156] ^ tw(s[n], s[n+1]),  output k = temper(s[k+312])
+// Tier 1: the first VR_TAPE outputs need s[0..VR_TAPE] and s[156..156+VR_TAPE):
+//   one 172-step pass of the seeding recurrence, kept in registers, written to
+//   a per-lane LDS tape (bank-conflict free: [slot][lane] layout).
+// Tier 2: a ray that draws more builds the whole 312-word state in a per-lane
+//   global scratch slab ([word][lane] so a wave's accesses coalesce) and
+//   continues with the textbook block twist.
+// ---------------------------------------------------------------------------
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned tea3(unsigned v0, unsigned v1) {
+  unsigned s0 = 0;
+#pragma unroll
+  for (int n = 0; n < 3; ++n) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+  }
+  return v0;
+}
+
+__device__ __forceinline__ u64 mt_step(u64 p, unsigned j) { return 6364136223846793005ull * (p ^ (p >> 62)) + j; }
+__device__ __forceinline__ u64 mt_twist(u64 a, u64 b, u64 c) {
+  u64 y = (a & 0xFFFFFFFF80000000ull) | (b & 0x7FFFFFFFull);
+  return c ^ (y >> 1) ^ ((b & 1ull) ? 0xB5026F5AA96619E9ull : 0ull);
+}
+__device__ __forceinline__ u64 mt_temper(u64 v) {
+  v ^= (v >> 29) & 0x5555555555555555ull;
+  v ^= (v << 17) & 0x71D67FFFEDA60000ull;
+  v ^= (v << 37) & 0xFFF7EEE000000000ull;
+  v ^= (v >> 43);
+  return v;
+}
+
+struct Rng {
+  unsigned seed;   // engine seed (32 bit)
+  unsigned k;      // index of the next output
+  unsigned pos;    // tier 2: position in the 312-word block, 0xFFFFFFFF = not built
+  u64 *tape;       // LDS, this lane's column: tape[slot * VR_BLOCK]
+  u64 *scratch;    // global, this lane's column: scratch[word * 64]
+};
+
+__device__ __forceinline__ void rng_init(Rng &r, unsigned seed, u64 *tapeLane, u64 *scratchLane) {
+  r.seed = seed;
+  r.k = 0;
+  r.pos = 0xFFFFFFFFu;
+  r.tape = tapeLane;
+  r.scratch = scratchLane;
+  u64 w[VR_TAPE + 1];
+  u64 x = seed;
+  w[0] = x;
+#pragma unroll
+  for (int j = 1; j <= VR_TAPE; ++j) {
+    x = mt_step(x, j);
+    w[j] = x;
+  }
+#pragma unroll 4
+  for (int j = VR_TAPE + 1; j < 156; ++j)
+    x = mt_step(x, j);
+#pragma unroll
+  for (int i = 0; i < VR_TAPE; ++i) {
+    x = mt_step(x, 156 + i);
+    tapeLane[i * VR_BLOCK] = mt_temper(mt_twist(w[i], w[i + 1], x));
+  }
+}
+
+__device__ __noinline__ void rng_tier2_build(Rng &r) {
+  u64 *s = r.scratch;
+  u64 x = r.seed;
+  s[0] = x;
+  for (int j = 1; j < 312; ++j) {
+    x = mt_step(x, j);
+    s[j * 64] = x;
+  }
+  r.pos = 312; // forces a twist on first use
+}
+
+__device__ __noinline__ void rng_tier2_twist(Rng &r) {
+  u64 *s = r.scratch;
+  u64 cur = s[0];
+  const u64 first = cur;
+  for (int i = 0; i < 156; ++i) {
+    u64 nxt = s[(i + 1) * 64];
+    s[i * 64] = mt_twist(cur, nxt, s[(i + 156) * 64]);
+    cur = nxt;
+  }
+  for (int i = 156; i < 311; ++i) {
+    u64 nxt = s[(i + 1) * 64];
+    s[i * 64] = mt_twist(cur, nxt, s[(i - 156) * 64]);
+    cur = nxt;
+  }
+  (void)first;
+  s[311 * 64] = mt_twist(cur, s[0], s[155 * 64]);
+}
+
+__device__ __forceinline__ u64 rng_next(Rng &r, unsigned &tier2Count) {
+  if (r.k < (unsigned)VR_TAPE) {
+    u64 v = r.tape[r.k * VR_BLOCK];
+    ++r.k;
+    return v;
+  }
+  if (r.pos == 0xFFFFFFFFu) {
+    rng_tier2_build(r);
+    rng_tier2_twist(r);
+    r.pos = r.k; // k == VR_TAPE < 312 here
+    ++tier2Count;
+  }
+  if (r.pos >= 312u) {
+    rng_tier2_twist(r);
+    r.pos = 0;
+  }
+  u64 v = mt_temper(r.scratch[r.pos * 64]);
+  ++r.pos;
+  ++r.k;
+  return v;
+}
+
+// libstdc++ std::uniform_real_distribution<float> on a 64-bit engine:
+// generate_canonical = float(u64) / 2^64, clamped below 1 (bits/random.tcc)
+__device__ __forceinline__ float canon_f32(u64 v) {
+  float f = (float)v * 5.42101086242752217e-20f; // 2^-64, exact scaling
+  return f >= 1.0f ? 0.99999994f : f;
+}
+__device__ __forceinline__ double canon_f64(u64 v) {
+  double f = (double)v * 5.42101086242752217e-20; // 2^-64
+  return f >= 1.0 ? 0.99999999999999989 : f;
+}
+
+// ---------------------------------------------------------------------------
+// Primitive tests — Embree 4.3.3 semantics restated
+// ---------------------------------------------------------------------------
+// oriented disc: plane hit, tnear <= t, dist^2 < r^2
+__device__ __forceinline__ bool hit_disc(const V3 &o, const V3 &d, float tnear, const float4 &c4, const V3 &n,
+                                         float &tOut) {
+  const float divisor = edot(d, n);
+  if (divisor == 0.f)
+    return false;
+  const V3 co = V3{c4.x - o.x, c4.y - o.y, c4.z - o.z};
+  const float t = edot(co, n) / divisor;
+  if (!(tnear <= t && t <= 3.402823466e+38f))
+    return false;
+  const V3 p = V3{o.x + d.x * t - c4.x, o.y + d.y * t - c4.y, o.z + d.z * t - c4.z};
+  const float dist2 = edot(p, p);
+  if (!(dist2 < c4.w * c4.w))
+    return false;
+  tOut = t;
+  return true;
+}
+
+__device__ __forceinline__ float xorsign(float v, float s) {
+  return __uint_as_float(__float_as_uint(v) ^ (__float_as_uint(s) & 0x80000000u));
+}
+
+// Moeller-Trumbore, Embree form: den != 0, U,V >= 0, U+V <= |den|, |den| tnear < T
+__device__ __forceinline__ bool hit_tri(const V3 &o, const V3 &d, float tnear, const V3 &v0, const V3 &e1,
+                                        const V3 &e2, const V3 &Ng, float &tOut) {
+  const V3 C = vsub(v0, o);
+  const V3 R = ecross(C, d);
+  const float den = edot(Ng, d);
+  const float absDen = fabsf(den);
+  const float U = xorsign(edot(R, e2), den);
+  const float V = xorsign(edot(R, e1), den);
+  if (!(den != 0.f && U >= 0.f && V >= 0.f && U + V <= absDen))
+    return false;
+  const float T = xorsign(edot(Ng, C), den);
+  if (!(absDen * tnear < T && T <= absDen * 3.402823466e+38f))
+    return false;
+  tOut = T / absDen;
+  return true;
+}
+
+struct HitRec {
+  float t;
+  int geom;       // -1 miss, 0 boundary, 1 geometry
+  unsigned prim;  // wall id, or ORIGINAL primitive id
+  unsigned pos;   // leaf position of the geometry primitive
+};
+
+template <int GEO>
+__device__ __forceinline__ void closest_hit(const TraceParams &p, const V3 &o, const V3 &d, float tnear,
+                                            HitRec &h) {
+  h.t = 3.402823466e+38f;
+  h.geom = -1;
+  h.prim = 0xFFFFFFFFu;
+  h.pos = 0;
+  // boundary: 8 wall triangles (scalar data, uniform control flow)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const Tri &w = p.wall[i];
+    float t;
+    if (hit_tri(o, d, tnear, mk(w.v0[0], w.v0[1], w.v0[2]), mk(w.e1[0], w.e1[1], w.e1[2]),
+                mk(w.e2[0], w.e2[1], w.e2[2]), mk(w.Ng[0], w.Ng[1], w.Ng[2]), t)) {
+      if (t < h.t) { // ascending wall id: ties keep the lower id
+        h.t = t;
+        h.geom = 0;
+        h.prim = (unsigned)i;
+      }
+    }
+  }
+  if (p.numPrims == 0)
+    return;
+  // geometry: stackless escape-link traversal
+  const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(p.nodes);
+  const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
+  V3 inv;
+  {
+    float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+    float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+    float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+    inv = V3{1.0f / dx, 1.0f / dy, 1.0f / dz};
+  }
+  const V3 oi = V3{o.x * inv.x, o.y * inv.y, o.z * inv.z};
+  unsigned node = 0;
+  while (node != VR_END) {
+    const float4 q0 = nodes[2 * node];
+    const float4 q1 = nodes[2 * node + 1];
+    // boxes are padded at build time by more than the rounding of this test
+    const float tx0 = __builtin_fmaf(q0.x, inv.x, -oi.x), tx1 = __builtin_fmaf(q1.x, inv.x, -oi.x);
+    const float ty0 = __builtin_fmaf(q0.y, inv.y, -oi.y), ty1 = __builtin_fmaf(q1.y, inv.y, -oi.y);
+    const float tz0 = __builtin_fmaf(q0.z, inv.z, -oi.z), tz1 = __builtin_fmaf(q1.z, inv.z, -oi.z);
+    const float tEntry = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
+    const float tExit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), h.t));
+    const unsigned link = __float_as_uint(q0.w);
+    const unsigned esc = __float_as_uint(q1.w);
+    if (tEntry <= tExit) {
+      if (link & VR_LEAF) {
+        const unsigned first = link & VR_LEAF_FIRST_MASK;
+        const unsigned cnt = (link >> 27) & 15u;
+        for (unsigned i = 0; i < cnt; ++i) {
+          const unsigned q = first + i;
+          float t;
+          unsigned orig;
+          bool ok;
+          if (GEO == 0) {
+            const float4 c4 = prims[2 * q];
+            const float4 n4 = prims[2 * q + 1];
+            orig = __float_as_uint(n4.w);
+            ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
+          } else {
+            const float4 a = prims[4 * q], b = prims[4 * q + 1], c = prims[4 * q + 2], e = prims[4 * q + 3];
+            orig = __float_as_uint(a.w);
+            ok = hit_tri(o, d, tnear, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(e.x, e.y, e.z), t);
+          }
+          // closest-hit rule: min t; ties -> boundary first, then lower original id
+          if (ok && (t < h.t || (t == h.t && h.geom == 1 && orig < h.prim))) {
+            h.t = t;
+            h.geom = 1;
+            h.prim = orig;
+            h.pos = q;
+          }
+        }
+        node = esc;
+      } else {
+        node = link;
+      }
+    } else {
+      node = esc;
+    }
+  }
+}
+
+// rayTraceKernel.hpp:462-507 (neighbour disk test)
+__device__ __forceinline__ bool local_disc_hit(const V3 &ro, const V3 &rd, const float4 &c4, const V3 &n) {
+  const float prod = vdot(n, rd);
+  if (prod > 0.f)
+    return false;
+  if (fabsf(prod) < 1e-6f)
+    return false;
+  const V3 c = V3{c4.x, c4.y, c4.z};
+  const float ddneg = vdot(c, n);
+  const float tt = (ddneg - vdot(n, ro)) / prod;
+  if (tt <= 0.f)
+    return false;
+  V3 hp = V3{rd.x * tt + ro.x, rd.y * tt + ro.y, rd.z * tt + ro.z};
+  hp.x = hp.x - c.x;
+  hp.y = hp.y - c.y;
+  hp.z = hp.z - c.z;
+  const float dist = sqrtf(vdot(hp, hp));
+  return c4.w > dist;
+}
+
+// rayReflection.hpp:13-29
+__device__ __forceinline__ V3 reflect_specular(const V3 &dir, const V3 &n) {
+  const V3 inv = V3{-dir.x, -dir.y, -dir.z};
+  const float f = 2 * vdot(n, inv);
+  return V3{f * n.x - inv.x, f * n.y - inv.y, f * n.z - inv.z};
+}
+
+// rayUtil.hpp:204-215 (the D==2 projection of fillRayDirection)
+template <int D> __device__ __forceinline__ V3 project_dir(V3 d) {
+  if (D == 2) {
+    if (d.z != 0.f) {
+      d.z = 0.f;
+      vnormalize(d);
+    }
+  }
+  return d;
+}
+
+// raySourceRandom.hpp:70-116: one power-cosine sample in the local frame.
+// glibc's sincosf/powf are stood in for by double-precision evaluation rounded
+// to float (differs from glibc in ~1 % of samples by 1 ulp).
+__device__ __forceinline__ void cosine_sample(float r1, float r2, float ee, float &cosTheta, float &sinTheta,
+                                              float &cosPhi, float &sinPhi) {
+  const float ang = (float)(3.14159265358979323846 * 2. * (double)r1);
+  double s, c;
+  sincos((double)ang, &s, &c);
+  sinPhi = (float)s;
+  cosPhi = (float)c;
+  cosTheta = (float)pow((double)r2, (double)ee);
+  sinTheta = (float)sqrt(1. - (double)(cosTheta * cosTheta));
+}
+
+} // namespace vr

@@ -1,0 +1,20 @@
+// vr_kernels.hpp — host-visible launchers of the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "vr_types.hpp"
+
+namespace vr {
+
+hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, unsigned grid, hipStream_t s);
+hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *org, const float *dir,
+                                  const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t,
+                                  hipStream_t s);
+hipError_t launch_debug_source(const TraceParams &p, int D, const unsigned long long *idx, unsigned n, float *org,
+                               float *dir, hipStream_t s);
+hipError_t launch_debug_rng(unsigned seed32, unsigned count, unsigned long long *scratch, unsigned long long *out,
+                            hipStream_t s);
+hipError_t launch_gather_flux(const unsigned long long *acc, const unsigned *leafOfOrig, unsigned n,
+                              unsigned long long *outAcc, hipStream_t s);
+
+} // namespace vr

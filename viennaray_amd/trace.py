@@ -1,0 +1,338 @@
+"""Host-side mirror of the reference front-end for the accelerated path.
+
+Same names, argument meaning and error behaviour as `viennaray::Trace<T,D>`,
+`TraceDisk`, `TraceTriangle`, `DiffuseParticle`, `SpecularParticle`,
+`TracingData` (reference: include/viennaray/rayTrace.hpp:15-180,
+rayTraceDisk.hpp:13-224, rayTraceTriangle.hpp:13-154, rayParticle.hpp:126-204,
+rayTracingData.hpp:16-219), driving the C ABI in include/viennaray_amd.h.
+The C++ façade with the reference's exact spelling lives in
+include/viennaray_amd/*.hpp; this module exists so the parity tests read like
+the reference's tests.
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import capi
+from .capi import VrError, TraceInfoPOD, ParticlePOD
+
+
+class BoundaryCondition(enum.IntEnum):  # rayBoundary.hpp:10-14
+    REFLECTIVE_BOUNDARY = 0
+    PERIODIC_BOUNDARY = 1
+    IGNORE_BOUNDARY = 2
+
+
+class TraceDirection(enum.IntEnum):  # rayUtil.hpp:40-47
+    POS_X = 0
+    NEG_X = 1
+    POS_Y = 2
+    NEG_Y = 3
+    POS_Z = 4
+    NEG_Z = 5
+
+
+class NormalizationType(enum.IntEnum):  # rayUtil.hpp:38
+    SOURCE = 0
+    MAX = 1
+
+
+class TracingDataMergeEnum(enum.IntEnum):  # rayTracingData.hpp:10-14
+    SUM = 0
+    APPEND = 1
+    AVERAGE = 2
+
+
+class DiffuseParticle:
+    """rayParticle.hpp:126-163"""
+    kind = 0
+
+    def __init__(self, stickingProbability, dataLabel, materialSticking=None):
+        self.stickingProbability = float(stickingProbability)
+        self.dataLabel = dataLabel
+        self.materialSticking = dict(materialSticking or {})
+
+    def getSourceDistributionPower(self):
+        return 1.0
+
+    def getLocalDataLabels(self):
+        return [self.dataLabel]
+
+
+class SpecularParticle:
+    """rayParticle.hpp:165-204"""
+    kind = 1
+
+    def __init__(self, stickingProbability, sourcePower, dataLabel, materialSticking=None):
+        self.stickingProbability = float(stickingProbability)
+        self.sourcePower = float(sourcePower)
+        self.dataLabel = dataLabel
+        self.materialSticking = dict(materialSticking or {})
+
+    def getSourceDistributionPower(self):
+        return self.sourcePower
+
+    def getLocalDataLabels(self):
+        return [self.dataLabel]
+
+
+class TracingData:
+    """Minimal rayTracingData.hpp:16-219: labelled vectors (merge type SUM)."""
+
+    def __init__(self):
+        self._vectors = []
+        self._labels = []
+
+    def setNumberOfVectorData(self, n):
+        self._vectors = [np.zeros(0, dtype=np.float32) for _ in range(n)]
+        self._labels = ["vectorData"] * n
+
+    def setVectorData(self, num, data, label="vectorData"):
+        self._vectors[num] = np.asarray(data, dtype=np.float32)
+        self._labels[num] = label
+
+    def getVectorData(self, key=0):
+        if isinstance(key, str):
+            key = self.getVectorDataIndex(key)
+        return self._vectors[key]
+
+    def getVectorDataLabel(self, i):
+        return self._labels[i]
+
+    def getVectorDataIndex(self, label):
+        for i, l in enumerate(self._labels):
+            if l == label:
+                return i
+        raise KeyError("Can not find vector data label in TracingData.")
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Trace:
+    """rayTrace.hpp:15-180 (NumericType = float)."""
+
+    def __init__(self, D=3, device=0):
+        self.D = D
+        self._L = capi.load()
+        h = C.c_void_p()
+        rc = self._L.vr_create(C.byref(h), device)
+        if rc != capi.VR_OK:
+            raise VrError("vr_create failed: no usable HIP device (the accelerated path has no CPU fallback)")
+        self._h = h
+        self._particle = None
+        self._localData = TracingData()
+        self._n = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.vr_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != capi.VR_OK:
+            raise VrError(self._L.vr_last_error(self._h).decode())
+
+    # --- setters (rayTrace.hpp:41-121) --------------------------------------
+    def setParticleType(self, particle):
+        self._particle = particle
+        pod = ParticlePOD()
+        pod.kind = particle.kind
+        pod.sticking = particle.stickingProbability
+        pod.sourcePower = particle.getSourceDistributionPower()
+        ms = particle.materialSticking
+        keep = None
+        if ms:
+            ids = (C.c_int32 * len(ms))(*ms.keys())
+            vals = (C.c_float * len(ms))(*ms.values())
+            pod.numMaterialSticking = len(ms)
+            pod.materialIds = ids
+            pod.materialSticking = vals
+            keep = (ids, vals)
+        self._check(self._L.vr_set_particle(self._h, C.byref(pod)))
+        del keep
+
+    def setBoundaryConditions(self, bcs):
+        a = (C.c_int32 * len(bcs))(*[int(b) for b in bcs])
+        self._check(self._L.vr_set_boundary_conditions(self._h, a, len(bcs)))
+
+    def setNumberOfRaysPerPoint(self, n):
+        self._check(self._L.vr_set_number_of_rays_per_point(self._h, int(n)))
+
+    def setNumberOfRaysFixed(self, n):
+        self._check(self._L.vr_set_number_of_rays_fixed(self._h, int(n)))
+
+    def setMaxReflections(self, n):
+        self._check(self._L.vr_set_max_reflections(self._h, int(n)))
+
+    def setMaxBoundaryHits(self, n):
+        self._check(self._L.vr_set_max_boundary_hits(self._h, int(n)))
+
+    def setSourceDirection(self, d):
+        self._check(self._L.vr_set_source_direction(self._h, int(d)))
+
+    def setPrimaryDirection(self, d):
+        a = np.ascontiguousarray(d, dtype=np.float32)
+        self._check(self._L.vr_set_primary_direction(self._h, _fptr(a)))
+
+    def setUseRandomSeeds(self, b):
+        self._check(self._L.vr_set_use_random_seeds(self._h, int(bool(b))))
+
+    def setRngSeed(self, s):
+        self._check(self._L.vr_set_rng_seed(self._h, int(s)))
+
+    def setMaterialIds(self, ids):
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        self._check(self._L.vr_set_material_ids(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), a.size))
+
+    # --- extensions used by the multi-GPU driver and the tests ---------------
+    def setRunNumber(self, r):
+        self._check(self._L.vr_set_run_number(self._h, int(r)))
+
+    def setRayRange(self, first, count):
+        self._check(self._L.vr_set_ray_range(self._h, int(first), int(count)))
+
+    # --- run ---------------------------------------------------------------
+    def apply(self):
+        if self._particle is None:
+            # checkSettings (rayTraceDisk.hpp:197-200)
+            raise VrError("No particle was specified in rayTrace. Aborting.")
+        self._check(self._L.vr_apply(self._h))
+        self._collect()
+
+    def applyPrepare(self):
+        self._check(self._L.vr_apply_prepare(self._h))
+
+    def applyLaunch(self):
+        self._check(self._L.vr_apply_launch(self._h))
+
+    def applyFinish(self, collect=True):
+        self._check(self._L.vr_apply_finish(self._h))
+        if collect:
+            self._collect()
+
+    def _collect(self):
+        labels = self._particle.getLocalDataLabels()
+        self._localData.setNumberOfVectorData(len(labels))
+        out = np.empty(self._n, dtype=np.float32)
+        self._check(self._L.vr_get_flux(self._h, _fptr(out), self._n))
+        self._localData.setVectorData(0, out, labels[0])
+
+    def getLocalData(self):
+        return self._localData
+
+    def getFluxF64(self):
+        out = np.empty(self._n, dtype=np.float64)
+        self._check(self._L.vr_get_flux_f64(self._h, out.ctypes.data_as(C.POINTER(C.c_double)), self._n))
+        return out
+
+    def getRayTraceInfo(self):
+        pod = TraceInfoPOD()
+        self._check(self._L.vr_get_trace_info(self._h, C.byref(pod)))
+        return pod
+
+    def normalizeFlux(self, flux, norm=NormalizationType.SOURCE):
+        f = np.ascontiguousarray(flux, dtype=np.float32).copy()
+        self._check(self._L.vr_normalize_flux(self._h, _fptr(f), f.size, int(norm)))
+        return f
+
+    def smoothFlux(self, flux, numNeighbors=1):
+        f = np.ascontiguousarray(flux, dtype=np.float32).copy()
+        self._check(self._L.vr_smooth_flux(self._h, _fptr(f), f.size, int(numNeighbors)))
+        return f
+
+    # --- geometry-derived values -----------------------------------------------
+    def getBoundingBox(self):
+        out = np.empty(6, dtype=np.float32)
+        self._check(self._L.vr_get_bounding_box(self._h, _fptr(out)))
+        return out.reshape(2, 3)
+
+    def getSourceArea(self):
+        return self._L.vr_get_source_area(self._h)
+
+    def fluxAccumulators(self):
+        """(device pointer, n) of the int64 fixed-point accumulators."""
+        p = C.c_void_p()
+        n = C.c_uint32()
+        self._check(self._L.vr_flux_accumulators(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # --- diagnostics ---------------------------------------------------------------
+    def debugIntersect(self, org, dirn, tnear=1e-4):
+        o = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirn, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        tn = np.full(n, tnear, dtype=np.float32)
+        g = np.empty(n, dtype=np.int32)
+        p = np.empty(n, dtype=np.uint32)
+        t = np.empty(n, dtype=np.float32)
+        self._check(self._L.vr_debug_intersect(self._h, _fptr(o), _fptr(d), _fptr(tn), n,
+                                               g.ctypes.data_as(C.POINTER(C.c_int32)),
+                                               p.ctypes.data_as(C.POINTER(C.c_uint32)), _fptr(t)))
+        return g, p, t
+
+    def debugSourceSample(self, idx, seed):
+        i = np.ascontiguousarray(idx, dtype=np.uint64)
+        o = np.empty((i.size, 3), dtype=np.float32)
+        d = np.empty((i.size, 3), dtype=np.float32)
+        self._check(self._L.vr_debug_source_sample(self._h, i.ctypes.data_as(C.POINTER(C.c_uint64)), i.size,
+                                                   int(seed), _fptr(o), _fptr(d)))
+        return o, d
+
+    def debugRngOutputs(self, idx, seed, count):
+        out = np.empty(count, dtype=np.uint64)
+        self._check(self._L.vr_debug_rng_outputs(self._h, int(idx), int(seed), count,
+                                                 out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def debugBvhStats(self):
+        a = (C.c_uint32 * 3)()
+        self._check(self._L.vr_debug_bvh_stats(self._h, a))
+        return dict(nodes=a[0], leaves=a[1], maxDepth=a[2])
+
+
+class TraceDisk(Trace):
+    """rayTraceDisk.hpp:13-224"""
+
+    def setGeometry(self, points, normals, gridDelta, diskRadius=0.0):
+        p = np.ascontiguousarray(points, dtype=np.float32)
+        n = np.ascontiguousarray(normals, dtype=np.float32)
+        if p.shape[1] == 2:  # 2-D points: z := 0 (rayGeometryDisk.hpp:148-151)
+            p = np.concatenate([p, np.zeros((p.shape[0], 1), np.float32)], axis=1)
+            n = np.concatenate([n, np.zeros((n.shape[0], 1), np.float32)], axis=1)
+        p = np.ascontiguousarray(p)
+        n = np.ascontiguousarray(n)
+        assert p.shape == n.shape, "Geometry: Points/Normals size mismatch"
+        self._n = p.shape[0]
+        self._check(self._L.vr_set_disks(self._h, _fptr(p), _fptr(n), self._n, float(gridDelta),
+                                         float(diskRadius), self.D))
+
+    def getDiskAreas(self):
+        out = np.empty(self._n, dtype=np.float32)
+        self._check(self._L.vr_get_disk_areas(self._h, _fptr(out), self._n))
+        return out
+
+    def getDiskRadius(self):
+        return self._L.vr_get_disk_radius(self._h)
+
+    def getNeighborCounts(self):
+        out = np.empty(self._n, dtype=np.uint32)
+        self._check(self._L.vr_get_neighbor_counts(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), self._n))
+        return out
+
+
+class TraceTriangle(Trace):
+    """rayTraceTriangle.hpp:13-154"""
+
+    def setGeometry(self, points, triangles, gridDelta):
+        v = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
+        self._n = t.shape[0]
+        self._check(self._L.vr_set_triangles(self._h, _fptr(v), v.shape[0],
+                                             t.ctypes.data_as(C.POINTER(C.c_uint32)), self._n,
+                                             float(gridDelta), self.D))
