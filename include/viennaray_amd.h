@@ -151,6 +151,10 @@ int vr_get_neighbor_counts(vr_context *ctx, uint32_t *out, uint32_t n);
  * replaces the device contents (e.g. after an all-reduce done elsewhere).    */
 #define VR_FLUX_FRAC_BITS 40
 int vr_flux_accumulators(vr_context *ctx, void **devPtr, uint32_t *n);
+/* Let the caller own the accumulator buffer instead (e.g. a torch int64 tensor
+ * handed to torch.distributed/RCCL): DEVICE pointer to n int64; NULL restores
+ * the library-owned buffer.  Must stay valid until replaced.                  */
+int vr_bind_flux_accumulators(vr_context *ctx, void *devPtr, uint32_t n);
 int vr_add_trace_info(vr_context *ctx, const vr_trace_info *other);
 /* stream the context launches on (hipStream_t as void*)                      */
 void *vr_stream(vr_context *ctx);

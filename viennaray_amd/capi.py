@@ -79,6 +79,7 @@ SIGNATURES = {
     "vr_get_disk_radius": (C.c_float, [_vp]),
     "vr_get_neighbor_counts": (C.c_int, [_vp, _u32p, C.c_uint32]),
     "vr_flux_accumulators": (C.c_int, [_vp, C.POINTER(_vp), _u32p]),
+    "vr_bind_flux_accumulators": (C.c_int, [_vp, _vp, C.c_uint32]),
     "vr_add_trace_info": (C.c_int, [_vp, C.POINTER(TraceInfoPOD)]),
     "vr_stream": (_vp, [_vp]),
     "vr_debug_intersect": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32, _i32p, _u32p, _fp]),

@@ -52,6 +52,7 @@ struct vr_context {
 
   HostGeometry geo;
   bool geometryDirty = true; // BVH / uploads need rebuilding
+  bool configDirty = true;   // bbox / walls / areas / sticking map need recomputing
   Bvh bvh;
   std::vector<uint32_t> leafOfOrig;
   std::vector<float> diskAreas;
@@ -91,6 +92,10 @@ struct vr_context {
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
   DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
   size_t scratchWaves = 0;
+  bool havePrimSticking = false;
+  unsigned long long *boundFlux = nullptr; // caller-owned accumulator buffer
+  uint32_t boundFluxN = 0;
+  unsigned long long *fluxOut() { return boundFlux ? boundFlux : dFluxOrig.p; }
 };
 
 #define VR_HIP(ctx, call)                                                                                              \
@@ -172,7 +177,9 @@ int vr_set_disks(vr_context *c, const float *points, const float *normals, uint3
   if (!c || !points || !normals || (D != 2 && D != 3) || n >= (1u << 27))
     return fail(c, VR_E_INVALID, "vr_set_disks: bad argument");
   host_set_disks(c->geo, points, normals, n, gridDelta, diskRadius, D);
+  c->boundFlux = nullptr;
   c->geometryDirty = true;
+  c->configDirty = true;
   c->prepared = c->haveResult = false;
   return VR_OK;
 }
@@ -185,7 +192,9 @@ int vr_set_triangles(vr_context *c, const float *verts, uint32_t nverts, const u
     if (tris[i] >= nverts)
       return fail(c, VR_E_INVALID, "vr_set_triangles: vertex index out of range");
   host_set_triangles(c->geo, verts, nverts, tris, ntris, gridDelta, D);
+  c->boundFlux = nullptr;
   c->geometryDirty = true;
+  c->configDirty = true;
   c->prepared = c->haveResult = false;
   return VR_OK;
 }
@@ -195,6 +204,7 @@ int vr_set_material_ids(vr_context *c, const int32_t *ids, uint32_t n) {
     return fail(c, VR_E_INVALID, "vr_set_material_ids: bad argument");
   c->geo.materialIds.assign(ids, ids + n);
   c->prepared = false;
+  c->configDirty = true;
   return VR_OK;
 }
 
@@ -208,6 +218,7 @@ int vr_set_boundary_conditions(vr_context *c, const int32_t *bcs, int n) {
     c->bcs[i] = bcs[i];
   }
   c->prepared = false;
+  c->configDirty = true;
   return VR_OK;
 }
 int vr_set_source_direction(vr_context *c, int d) {
@@ -215,6 +226,7 @@ int vr_set_source_direction(vr_context *c, int d) {
     return fail(c, VR_E_INVALID, "vr_set_source_direction: bad argument");
   c->sourceDirection = d;
   c->prepared = false;
+  c->configDirty = true;
   return VR_OK;
 }
 int vr_set_primary_direction(vr_context *c, const float *d) {
@@ -227,6 +239,7 @@ int vr_set_primary_direction(vr_context *c, const float *d) {
     c->usePrimaryDirection = false;
   }
   c->prepared = false;
+  c->configDirty = true;
   return VR_OK;
 }
 int vr_set_particle(vr_context *c, const vr_particle *p) {
@@ -244,6 +257,7 @@ int vr_set_particle(vr_context *c, const vr_particle *p) {
   }
   c->haveParticle = true;
   c->prepared = false;
+  c->configDirty = true;
   return VR_OK;
 }
 int vr_set_number_of_rays_per_point(vr_context *c, uint64_t n) {
@@ -331,22 +345,23 @@ int vr_apply_prepare(vr_context *c) {
     c->info.warning = 1;
 
   const auto t0 = std::chrono::steady_clock::now();
-  // bounding box, trace settings, boundary (rayTraceDisk.hpp:21-27)
-  for (int k = 0; k < 3; ++k) {
-    c->bbLo[k] = c->geo.minC[k];
-    c->bbHi[k] = c->geo.maxC[k];
-  }
-  host_adjust_bbox(c->bbLo, c->bbHi, D, dir, c->geo.geo == 0 ? c->geo.diskRadius : c->geo.gridDelta);
-  c->ts = host_trace_settings(dir);
   TraceParams &p = c->params;
-  host_build_walls(c->bbLo, c->bbHi, c->ts[1], c->ts[2], p.wall);
-  // rayBoundary.hpp:23-25: conditions are picked by AXIS
-  c->boundaryConds[0] = c->bcs[c->ts[1]];
-  c->boundaryConds[1] = (D == 2 && c->ts[2] >= 2) ? 0 : c->bcs[c->ts[2]];
-  if (c->geo.geo == 0)
-    host_disk_areas(c->geo, c->boundaryConds, c->ts[1], c->ts[2], c->diskAreas);
-  // SourceRandom::getSourceArea (raySourceRandom.hpp:40-47)
-  {
+  const bool redoConfig = c->configDirty || c->geometryDirty;
+  if (redoConfig) {
+    // bounding box, trace settings, boundary (rayTraceDisk.hpp:21-27)
+    for (int k = 0; k < 3; ++k) {
+      c->bbLo[k] = c->geo.minC[k];
+      c->bbHi[k] = c->geo.maxC[k];
+    }
+    host_adjust_bbox(c->bbLo, c->bbHi, D, dir, c->geo.geo == 0 ? c->geo.diskRadius : c->geo.gridDelta);
+    c->ts = host_trace_settings(dir);
+    host_build_walls(c->bbLo, c->bbHi, c->ts[1], c->ts[2], p.wall);
+    // rayBoundary.hpp:23-25: conditions are picked by AXIS
+    c->boundaryConds[0] = c->bcs[c->ts[1]];
+    c->boundaryConds[1] = (D == 2 && c->ts[2] >= 2) ? 0 : c->bcs[c->ts[2]];
+    if (c->geo.geo == 0)
+      host_disk_areas(c->geo, c->boundaryConds, c->ts[1], c->ts[2], c->diskAreas);
+    // SourceRandom::getSourceArea (raySourceRandom.hpp:40-47)
     const int f = c->ts[1], s = c->ts[2];
     c->sourceArea = D == 2 ? (c->bbHi[f] - c->bbLo[f]) : (c->bbHi[f] - c->bbLo[f]) * (c->bbHi[s] - c->bbLo[s]);
   }
@@ -389,8 +404,9 @@ int vr_apply_prepare(vr_context *c) {
     c->geometryDirty = false;
   }
   // per-primitive sticking from the material map (gpu::Particle-style, rayParticle.hpp:208-218)
-  const float *dStick = nullptr;
-  if (!c->matStickIds.empty()) {
+  if (redoConfig)
+    c->havePrimSticking = false;
+  if (redoConfig && !c->matStickIds.empty()) {
     std::vector<float> ps(N);
     for (uint32_t q = 0; q < N; ++q) {
       const uint32_t o = c->bvh.order[q];
@@ -403,8 +419,10 @@ int vr_apply_prepare(vr_context *c) {
     }
     VR_HIP(c, c->dPrimSticking.ensure(N));
     VR_HIP(c, hipMemcpy(c->dPrimSticking.p, ps.data(), (size_t)N * 4, hipMemcpyHostToDevice));
-    dStick = c->dPrimSticking.p;
+    c->havePrimSticking = true;
   }
+  const float *dStick = c->havePrimSticking ? c->dPrimSticking.p : nullptr;
+  c->configDirty = false;
 
   // launch geometry: enough blocks to fill the chip; the kernel is a work queue
   c->grid = (unsigned)c->numCUs * 4u;
@@ -466,7 +484,9 @@ int vr_apply_prepare(vr_context *c) {
     p.bbLo[k] = c->bbLo[k];
     p.bbHi[k] = c->bbHi[k];
   }
-  c->buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (redoConfig)
+    c->buildSeconds = secs; // a cheap re-prepare (new seed / ray range only) keeps the last build time
   c->prepared = true;
   c->launched = false;
   c->haveResult = false;
@@ -486,7 +506,7 @@ int vr_apply_launch(vr_context *c) {
   if (c->params.rayEnd > c->params.rayFirst)
     VR_HIP(c, launch_trace(c->params, c->geo.D, c->geo.geo, c->particleKind, c->grid, c->stream));
   VR_HIP(c, hipEventRecord(c->ev1, c->stream));
-  VR_HIP(c, launch_gather_flux(c->dFluxAcc.p, c->dLeafOfOrig.p, N, c->dFluxOrig.p, c->stream));
+  VR_HIP(c, launch_gather_flux(c->dFluxAcc.p, c->dLeafOfOrig.p, N, c->fluxOut(), c->stream));
   c->launched = true;
   return VR_OK;
 }
@@ -543,7 +563,7 @@ int vr_get_flux_f64(vr_context *c, double *out, uint32_t n) {
     return fail(c, VR_E_INVALID, "vr_get_flux: size mismatch");
   VR_HIP(c, hipSetDevice(c->device));
   std::vector<unsigned long long> acc(n);
-  VR_HIP(c, hipMemcpy(acc.data(), c->dFluxOrig.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  VR_HIP(c, hipMemcpy(acc.data(), c->fluxOut(), (size_t)n * 8, hipMemcpyDeviceToHost));
   const double scale = std::ldexp(1.0, -VR_FLUX_FRAC_BITS);
   for (uint32_t i = 0; i < n; ++i)
     out[i] = (double)acc[i] * scale;
@@ -588,9 +608,19 @@ int vr_flux_accumulators(vr_context *c, void **devPtr, uint32_t *n) {
     return VR_E_INVALID;
   if (!c->haveResult)
     return fail(c, VR_E_STATE, "vr_flux_accumulators: no result");
-  *devPtr = c->dFluxOrig.p;
+  *devPtr = c->fluxOut();
   if (n)
     *n = c->geo.numPrims;
+  return VR_OK;
+}
+
+int vr_bind_flux_accumulators(vr_context *c, void *devPtr, uint32_t n) {
+  if (!c)
+    return VR_E_INVALID;
+  if (devPtr && n != c->geo.numPrims)
+    return fail(c, VR_E_INVALID, "vr_bind_flux_accumulators: size mismatch (set the geometry first)");
+  c->boundFlux = (unsigned long long *)devPtr;
+  c->boundFluxN = devPtr ? n : 0;
   return VR_OK;
 }
 

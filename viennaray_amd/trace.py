@@ -262,6 +262,10 @@ class Trace:
         self._check(self._L.vr_flux_accumulators(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def bindFluxAccumulators(self, dev_ptr, n):
+        """Use a caller-owned device buffer of n int64 (e.g. a torch tensor)."""
+        self._check(self._L.vr_bind_flux_accumulators(self._h, C.c_void_p(dev_ptr), int(n)))
+
     # --- diagnostics ---------------------------------------------------------------
     def debugIntersect(self, org, dirn, tnear=1e-4):
         o = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
