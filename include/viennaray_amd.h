@@ -59,7 +59,8 @@ typedef struct vr_trace_info {
   uint64_t raysTerminated;
   double time;          /* seconds: BVH build + ray loop, like the reference (Q10) */
   double timeBuild;     /* seconds: BVH build part of `time`                       */
-  double timeTrace;     /* seconds: trace kernel only (HIP events)                 */
+  double timeTrace;     /* seconds: device pipeline gen+sort+trace (HIP events)     */
+  double timeTraceKernel; /* seconds: the trace kernel(s) alone (HIP events)        */
   int32_t warning;
   int32_t error;
 } vr_trace_info;

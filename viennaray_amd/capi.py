@@ -24,6 +24,7 @@ class TraceInfoPOD(C.Structure):
                 ("particleHits", C.c_uint64), ("boundaryHits", C.c_uint64),
                 ("reflections", C.c_uint64), ("raysTerminated", C.c_uint64),
                 ("time", C.c_double), ("timeBuild", C.c_double), ("timeTrace", C.c_double),
+                ("timeTraceKernel", C.c_double),
                 ("warning", C.c_int32), ("error", C.c_int32)]
 
     def as_dict(self):

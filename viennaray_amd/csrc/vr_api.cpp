@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -92,6 +93,17 @@ struct vr_context {
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
   DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
   size_t scratchWaves = 0;
+  // ray stream (one batch)
+  DevBuf<float> dGenA, dGenB, dRayA, dRayB, dWalls;
+  DevBuf<unsigned long long> dGenTape, dRayTape;
+  DevBuf<uint32_t> dGenBin, dBinHist, dBinCursor, dScanTmp;
+  uint32_t batchCap = 0;      // rays per batch the buffers hold
+  uint32_t numBins = 0;
+  uint64_t rayFirstLaunch = 0, rayEndLaunch = 0;
+  bool absorb = true;
+  std::vector<hipEvent_t> evK; // trace-kernel event pairs, one per batch
+  double traceKernelSeconds = 0.0;
+  size_t numBatches = 0;
   bool havePrimSticking = false;
   unsigned long long *boundFlux = nullptr; // caller-owned accumulator buffer
   uint32_t boundFluxN = 0;
@@ -160,6 +172,19 @@ void vr_destroy(vr_context *c) {
   c->dFluxOrig.release();
   c->dCounters.release();
   c->dScratch.release();
+  c->dGenA.release();
+  c->dGenB.release();
+  c->dRayA.release();
+  c->dRayB.release();
+  c->dWalls.release();
+  c->dGenTape.release();
+  c->dRayTape.release();
+  c->dGenBin.release();
+  c->dBinHist.release();
+  c->dBinCursor.release();
+  c->dScanTmp.release();
+  for (auto e : c->evK)
+    (void)hipEventDestroy(e);
   if (c->ev0)
     (void)hipEventDestroy(c->ev0);
   if (c->ev1)
@@ -355,7 +380,19 @@ int vr_apply_prepare(vr_context *c) {
     }
     host_adjust_bbox(c->bbLo, c->bbHi, D, dir, c->geo.geo == 0 ? c->geo.diskRadius : c->geo.gridDelta);
     c->ts = host_trace_settings(dir);
-    host_build_walls(c->bbLo, c->bbHi, c->ts[1], c->ts[2], p.wall);
+    {
+      Tri walls[8];
+      host_build_walls(c->bbLo, c->bbHi, c->ts[1], c->ts[2], walls);
+      float tbl[96];
+      for (int i = 0; i < 8; ++i) {
+        std::memcpy(tbl + 12 * i, walls[i].v0, 12);
+        std::memcpy(tbl + 12 * i + 3, walls[i].e1, 12);
+        std::memcpy(tbl + 12 * i + 6, walls[i].e2, 12);
+        std::memcpy(tbl + 12 * i + 9, walls[i].Ng, 12);
+      }
+      VR_HIP(c, c->dWalls.ensure(96));
+      VR_HIP(c, hipMemcpy(c->dWalls.p, tbl, sizeof(tbl), hipMemcpyHostToDevice));
+    }
     // rayBoundary.hpp:23-25: conditions are picked by AXIS
     c->boundaryConds[0] = c->bcs[c->ts[1]];
     c->boundaryConds[1] = (D == 2 && c->ts[2] >= 2) ? 0 : c->bcs[c->ts[2]];
@@ -424,14 +461,6 @@ int vr_apply_prepare(vr_context *c) {
   const float *dStick = c->havePrimSticking ? c->dPrimSticking.p : nullptr;
   c->configDirty = false;
 
-  // launch geometry: enough blocks to fill the chip; the kernel is a work queue
-  c->grid = (unsigned)c->numCUs * 4u;
-  const size_t waves = (size_t)c->grid * (VR_BLOCK / 64);
-  if (waves > c->scratchWaves) {
-    VR_HIP(c, c->dScratch.ensure(waves * 312u * 64u));
-    c->scratchWaves = waves;
-  }
-
   const uint64_t numRays = c->numRaysFixed == 0 ? (uint64_t)N * c->numRaysPerPoint : c->numRaysFixed;
   c->numRaysLast = numRays;
   uint64_t first = 0, last = numRays;
@@ -439,33 +468,105 @@ int vr_apply_prepare(vr_context *c) {
     first = std::min(c->rayFirst, numRays);
     last = std::min(numRays, first + c->rayCount);
   }
+  c->rayFirstLaunch = first;
+  c->rayEndLaunch = last;
   uint32_t seed = c->runNumber + c->rngSeed; // rayTraceKernel.hpp:100
   if (c->useRandomSeed) {
     std::random_device rd;
     seed = (uint32_t)rd();
   }
+  // ABSORB: every hit takes the whole weight -> nothing after the first
+  // surface hit is observable
+  c->absorb = c->sticking >= 1.f;
+  for (float v : c->matStickVals)
+    c->absorb = c->absorb && v >= 1.f;
+
+  // ---- ray-stream buffers: batches of up to 2^25 rays --------------------------
+  const uint64_t span = last - first;
+  uint32_t cap = (uint32_t)std::min<uint64_t>(span, 1ull << 25);
+  if (const char *e = std::getenv("VR_BATCH_RAYS"))
+    cap = (uint32_t)std::min<uint64_t>(span, std::max<long long>(256, std::atoll(e)));
+  cap = std::max<uint32_t>(cap, 1u);
+  if (cap > c->batchCap || (!c->absorb && c->dGenTape.cap < (size_t)cap * VR_NPRE)) {
+    VR_HIP(c, c->dGenA.ensure((size_t)cap * 4));
+    VR_HIP(c, c->dGenB.ensure((size_t)cap * 4));
+    VR_HIP(c, c->dRayA.ensure((size_t)cap * 4));
+    VR_HIP(c, c->dRayB.ensure((size_t)cap * 4));
+    VR_HIP(c, c->dGenBin.ensure(cap));
+    if (!c->absorb) {
+      VR_HIP(c, c->dGenTape.ensure((size_t)cap * VR_NPRE));
+      VR_HIP(c, c->dRayTape.ensure((size_t)cap * VR_NPRE));
+    }
+    c->batchCap = std::max(c->batchCap, cap);
+  }
+  // source-plane cells: about one per 32 rays of a batch, at most ~4 per primitive
+  {
+    uint64_t target = std::min<uint64_t>({(uint64_t)4 * N, std::max<uint64_t>(cap / 32, 1), 1ull << 22});
+    int T1, T2;
+    if (D == 2) {
+      T1 = (int)std::min<uint64_t>(std::max<uint64_t>(target, 1), 1u << 20);
+      T2 = 1;
+    } else {
+      T1 = T2 = (int)std::min<double>(2048.0, std::max(1.0, std::ceil(std::sqrt((double)target))));
+    }
+    if (const char *e = std::getenv("VR_BINS_PER_AXIS")) {
+      T1 = std::max(1, std::min(D == 2 ? (1 << 20) : 2048, std::atoi(e)));
+      T2 = D == 2 ? 1 : T1;
+    }
+    uint32_t nb;
+    if (D == 2) {
+      nb = (uint32_t)T1;
+    } else {
+      uint32_t P = 1;
+      while ((int)P < std::max(T1, T2))
+        P <<= 1;
+      nb = P * P;
+    }
+    c->numBins = nb;
+    p.binT1 = T1;
+    p.binT2 = T2;
+    VR_HIP(c, c->dBinHist.ensure(nb));
+    VR_HIP(c, c->dBinCursor.ensure(nb));
+    VR_HIP(c, c->dScanTmp.ensure(2 * ((size_t)nb / 2048 + 2) + 16));
+  }
+
+  // launch geometry of the persistent kernels
+  c->grid = (unsigned)c->numCUs * (unsigned)std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->particleKind, c->absorb));
+  const size_t waves = (size_t)std::max(c->grid, (unsigned)c->numCUs * 8u) * (VR_BLOCK / 64);
+  if (waves > c->scratchWaves) {
+    VR_HIP(c, c->dScratch.ensure(waves * 312u * 64u));
+    c->scratchWaves = waves;
+  }
+
   p.nodes = c->dNodes.p;
   p.prims = c->dPrims.p;
   p.nbOff = c->dNbOff.p;
   p.nbIds = c->dNbIds.p;
   p.primSticking = dStick;
+  p.wallTable = c->dWalls.p;
   p.fluxAcc = c->dFluxAcc.p;
   p.counters = c->dCounters.p;
   p.workCounter = c->dCounters.p + 8;
   p.rngScratch = c->dScratch.p;
-  p.rayFirst = first;
-  p.rayEnd = last;
+  p.genA = c->dGenA.p;
+  p.genB = c->dGenB.p;
+  p.genTape = c->absorb ? nullptr : c->dGenTape.p;
+  p.genBin = c->dGenBin.p;
+  p.rayA = c->dRayA.p;
+  p.rayB = c->dRayB.p;
+  p.rayTape = c->absorb ? nullptr : c->dRayTape.p;
+  p.binHist = c->dBinHist.p;
+  p.binCursor = c->dBinCursor.p;
+  p.idxList = nullptr;
+  p.batchFirst = first;
+  p.batchCount = 0;
+  p.batchCap = c->batchCap;
+  p.numBins = c->numBins;
   p.seed = seed;
   p.numPrims = N;
   p.maxReflections = c->maxReflections;
   p.maxBoundaryHits = c->maxBoundaryHits;
-  {
-    const uint64_t span = last - first;
-    uint64_t chunk = 2048;
-    while (chunk > VR_BLOCK && span / chunk < (uint64_t)c->grid * 4)
-      chunk >>= 1;
-    p.chunk = (uint32_t)chunk;
-  }
+  p.chunk = 64;
   p.rayDir = c->ts[0];
   p.firstDir = c->ts[1];
   p.secondDir = c->ts[2];
@@ -480,16 +581,51 @@ int vr_apply_prepare(vr_context *c) {
     host_orthonormal_basis(c->primaryDirection, p.basis);
   else
     std::memset(p.basis, 0, sizeof(p.basis));
-  for (int k = 0; k < 3; ++k) {
-    p.bbLo[k] = c->bbLo[k];
-    p.bbHi[k] = c->bbHi[k];
-  }
+  p.srcCoord = c->ts[3] ? c->bbHi[c->ts[0]] : c->bbLo[c->ts[0]];
+  p.lo1 = c->bbLo[c->ts[1]];
+  p.hi1 = c->bbHi[c->ts[1]];
+  p.lo2 = c->bbLo[c->ts[2]];
+  p.hi2 = c->bbHi[c->ts[2]];
+  p.binInv1 = (p.hi1 > p.lo1) ? (float)p.binT1 / (p.hi1 - p.lo1) : 0.f;
+  p.binInv2 = (p.hi2 > p.lo2) ? (float)p.binT2 / (p.hi2 - p.lo2) : 0.f;
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (redoConfig)
     c->buildSeconds = secs; // a cheap re-prepare (new seed / ray range only) keeps the last build time
   c->prepared = true;
   c->launched = false;
   c->haveResult = false;
+  return VR_OK;
+}
+
+// one batch of the ray stream: generate -> bin -> sort -> trace
+static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batchNo) {
+  TraceParams p = c->params;
+  p.batchFirst = first;
+  p.batchCount = count;
+  {
+    // rays one wave pulls per queue access: enough grabs for balance, few enough
+    // to keep the queue word cold
+    const uint64_t waves = (uint64_t)c->grid * (VR_BLOCK / 64);
+    uint64_t chunk = 1024;
+    while (chunk > 64 && (uint64_t)count / chunk < waves * 8)
+      chunk >>= 1;
+    p.chunk = (uint32_t)chunk;
+  }
+  const bool tape = !c->absorb;
+  VR_HIP(c, hipMemsetAsync(c->dBinHist.p, 0, (size_t)c->numBins * 4, c->stream));
+  VR_HIP(c, hipMemsetAsync(c->dBinCursor.p, 0, (size_t)c->numBins * 4, c->stream));
+  VR_HIP(c, hipMemsetAsync(p.workCounter, 0, 8, c->stream));
+  VR_HIP(c, launch_gen(p, c->geo.D, tape, (unsigned)c->numCUs * 8u, c->stream));
+  VR_HIP(c, launch_scan(c->dBinHist.p, c->numBins, c->dScanTmp.p, c->stream));
+  VR_HIP(c, launch_scatter(p, tape, c->stream));
+  while (c->evK.size() < 2 * (batchNo + 1)) {
+    hipEvent_t e;
+    VR_HIP(c, hipEventCreate(&e));
+    c->evK.push_back(e);
+  }
+  VR_HIP(c, hipEventRecord(c->evK[2 * batchNo], c->stream));
+  VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->particleKind, c->absorb, c->grid, c->stream));
+  VR_HIP(c, hipEventRecord(c->evK[2 * batchNo + 1], c->stream));
   return VR_OK;
 }
 
@@ -503,8 +639,14 @@ int vr_apply_launch(vr_context *c) {
   VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)N * 8, c->stream));
   VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 16 * 8, c->stream));
   VR_HIP(c, hipEventRecord(c->ev0, c->stream));
-  if (c->params.rayEnd > c->params.rayFirst)
-    VR_HIP(c, launch_trace(c->params, c->geo.D, c->geo.geo, c->particleKind, c->grid, c->stream));
+  c->numBatches = 0;
+  for (uint64_t f = c->rayFirstLaunch; f < c->rayEndLaunch; f += c->batchCap) {
+    const uint32_t cnt = (uint32_t)std::min<uint64_t>(c->batchCap, c->rayEndLaunch - f);
+    int r = run_batch(c, f, cnt, c->numBatches);
+    if (r != VR_OK)
+      return r;
+    ++c->numBatches;
+  }
   VR_HIP(c, hipEventRecord(c->ev1, c->stream));
   VR_HIP(c, launch_gather_flux(c->dFluxAcc.p, c->dLeafOfOrig.p, N, c->fluxOut(), c->stream));
   c->launched = true;
@@ -532,6 +674,13 @@ int vr_apply_finish(vr_context *c) {
   i.reflections = cnt[C_REFLECTIONS];
   i.raysTerminated = cnt[C_TERMINATED];
   i.timeTrace = ms * 1e-3;
+  double kms = 0.0;
+  for (size_t b = 0; b < c->numBatches; ++b) {
+    float m = 0.f;
+    VR_HIP(c, hipEventElapsedTime(&m, c->evK[2 * b], c->evK[2 * b + 1]));
+    kms += m;
+  }
+  i.timeTraceKernel = kms * 1e-3;
   i.timeBuild = c->buildSeconds;
   i.time = i.timeBuild + i.timeTrace;
   ++c->runNumber; // rayTraceDisk.hpp:54
@@ -757,23 +906,30 @@ int vr_debug_source_sample(vr_context *c, const uint64_t *idx, uint32_t n, uint3
     if (r != VR_OK)
       return r;
   }
-  if ((size_t)((n + 63) / 64) > c->scratchWaves)
-    return fail(c, VR_E_INVALID, "vr_debug_source_sample: too many rays for one call");
+  if (n > c->batchCap)
+    return fail(c, VR_E_INVALID, "vr_debug_source_sample: more rays than one batch holds");
   TraceParams p = c->params;
   p.seed = seed;
+  p.batchCount = n;
+  p.genBin = nullptr; // no binning
   DevBuf<unsigned long long> dI;
-  DevBuf<float> dO, dD;
   VR_HIP(c, dI.ensure(n));
-  VR_HIP(c, dO.ensure((size_t)n * 3));
-  VR_HIP(c, dD.ensure((size_t)n * 3));
   VR_HIP(c, hipMemcpy(dI.p, idx, (size_t)n * 8, hipMemcpyHostToDevice));
-  VR_HIP(c, launch_debug_source(p, c->geo.D, dI.p, n, dO.p, dD.p, c->stream));
+  p.idxList = dI.p;
+  VR_HIP(c, launch_gen(p, c->geo.D, false, (unsigned)c->numCUs * 8u, c->stream));
   VR_HIP(c, hipStreamSynchronize(c->stream));
-  VR_HIP(c, hipMemcpy(org, dO.p, (size_t)n * 12, hipMemcpyDeviceToHost));
-  VR_HIP(c, hipMemcpy(dir, dD.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+  std::vector<float> A((size_t)n * 4), B((size_t)n * 4);
+  VR_HIP(c, hipMemcpy(A.data(), c->dGenA.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+  VR_HIP(c, hipMemcpy(B.data(), c->dGenB.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+  for (uint32_t i = 0; i < n; ++i) {
+    org[3 * i] = A[4 * (size_t)i];
+    org[3 * i + 1] = A[4 * (size_t)i + 1];
+    org[3 * i + 2] = A[4 * (size_t)i + 2];
+    dir[3 * i] = A[4 * (size_t)i + 3];
+    dir[3 * i + 1] = B[4 * (size_t)i];
+    dir[3 * i + 2] = B[4 * (size_t)i + 1];
+  }
   dI.release();
-  dO.release();
-  dD.release();
   return VR_OK;
 }
 

@@ -83,6 +83,8 @@ __device__ __forceinline__ u64 mt_temper(u64 v) {
 struct Rng {
   unsigned seed;   // engine seed (32 bit)
   unsigned k;      // index of the next output
+  unsigned k0;     // index of the output held in tape slot 0
+  unsigned nTape;  // number of outputs in the tape
   unsigned pos;    // tier 2: position in the 312-word block, 0xFFFFFFFF = not built
   u64 *tape;       // LDS, this lane's column: tape[slot * VR_BLOCK]
   u64 *scratch;    // global, this lane's column: scratch[word * 64]
@@ -91,6 +93,8 @@ struct Rng {
 __device__ __forceinline__ void rng_init(Rng &r, unsigned seed, u64 *tapeLane, u64 *scratchLane) {
   r.seed = seed;
   r.k = 0;
+  r.k0 = 0;
+  r.nTape = VR_TAPE;
   r.pos = 0xFFFFFFFFu;
   r.tape = tapeLane;
   r.scratch = scratchLane;
@@ -142,15 +146,20 @@ __device__ __noinline__ void rng_tier2_twist(Rng &r) {
 }
 
 __device__ __forceinline__ u64 rng_next(Rng &r, unsigned &tier2Count) {
-  if (r.k < (unsigned)VR_TAPE) {
-    u64 v = r.tape[r.k * VR_BLOCK];
+  if (r.k - r.k0 < r.nTape) {
+    u64 v = r.tape[(r.k - r.k0) * VR_BLOCK];
     ++r.k;
     return v;
   }
   if (r.pos == 0xFFFFFFFFu) {
     rng_tier2_build(r);
     rng_tier2_twist(r);
-    r.pos = r.k; // k == VR_TAPE < 312 here
+    unsigned skip = r.k; // outputs already consumed from the tape
+    while (skip >= 312u) { // (only after > 312 rejected source samples)
+      rng_tier2_twist(r);
+      skip -= 312u;
+    }
+    r.pos = skip;
     ++tier2Count;
   }
   if (r.pos >= 312u) {
@@ -224,24 +233,46 @@ struct HitRec {
   unsigned pos;   // leaf position of the geometry primitive
 };
 
+// Exact pre-test for an axis-aligned wall at coordinate W on axis a: the
+// Moeller-Trumbore depth test can only pass when (W - o_a) and d_a have the
+// same strict sign (the other two components of the wall's Ng are exactly 0),
+// so walls failing it are skipped without changing any result.
+__device__ __forceinline__ bool wall_reachable(float W, float oa, float da) {
+  const float c = W - oa;
+  return (c > 0.f && da > 0.f) || (c < 0.f && da < 0.f);
+}
+
 template <int GEO>
-__device__ __forceinline__ void closest_hit(const TraceParams &p, const V3 &o, const V3 &d, float tnear,
-                                            HitRec &h) {
+__device__ __forceinline__ void closest_hit(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
+                                            const V3 &d, float tnear, HitRec &h) {
   h.t = 3.402823466e+38f;
   h.geom = -1;
   h.prim = 0xFFFFFFFFu;
   h.pos = 0;
-  // boundary: 8 wall triangles (scalar data, uniform control flow)
+  // boundary: 8 wall triangles {v0,e1,e2,Ng} in LDS; pairs (0,1) (2,3) lie on the
+  // firstDir min/max planes, (4,5) (6,7) on the secondDir min/max planes
+  {
+    const float o1 = getc(o, p.firstDir), d1 = getc(d, p.firstDir);
+    const float o2 = getc(o, p.secondDir), d2 = getc(d, p.secondDir);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const Tri &w = p.wall[i];
-    float t;
-    if (hit_tri(o, d, tnear, mk(w.v0[0], w.v0[1], w.v0[2]), mk(w.e1[0], w.e1[1], w.e1[2]),
-                mk(w.e2[0], w.e2[1], w.e2[2]), mk(w.Ng[0], w.Ng[1], w.Ng[2]), t)) {
-      if (t < h.t) { // ascending wall id: ties keep the lower id
-        h.t = t;
-        h.geom = 0;
-        h.prim = (unsigned)i;
+    for (int pair = 0; pair < 4; ++pair) {
+      const float *w0 = wallS + 24 * pair;
+      const int axis = pair < 2 ? p.firstDir : p.secondDir;
+      const float W = axis == 0 ? w0[0] : (axis == 1 ? w0[1] : w0[2]);
+      if (!wall_reachable(W, pair < 2 ? o1 : o2, pair < 2 ? d1 : d2))
+        continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float *w = w0 + 12 * j;
+        float t;
+        if (hit_tri(o, d, tnear, mk(w[0], w[1], w[2]), mk(w[3], w[4], w[5]), mk(w[6], w[7], w[8]),
+                    mk(w[9], w[10], w[11]), t)) {
+          if (t < h.t) { // ascending wall id: ties keep the lower id
+            h.t = t;
+            h.geom = 0;
+            h.prim = (unsigned)(2 * pair + j);
+          }
+        }
       }
     }
   }

@@ -6,12 +6,16 @@
 
 namespace vr {
 
-hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, unsigned grid, hipStream_t s);
+hipError_t launch_gen(const TraceParams &p, int D, bool withTape, unsigned maxBlocks, hipStream_t s);
+hipError_t launch_scan(unsigned *data, unsigned n, unsigned *tmp, hipStream_t s);
+hipError_t launch_scatter(const TraceParams &p, bool withTape, hipStream_t s);
+hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, bool absorb, unsigned grid,
+                        hipStream_t s);
+// resident 256-thread blocks per CU of the trace kernel instantiation (occupancy API)
+int trace_blocks_per_cu(int D, int geo, int particle, bool absorb);
 hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *org, const float *dir,
                                   const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t,
                                   hipStream_t s);
-hipError_t launch_debug_source(const TraceParams &p, int D, const unsigned long long *idx, unsigned n, float *org,
-                               float *dir, hipStream_t s);
 hipError_t launch_debug_rng(unsigned seed32, unsigned count, unsigned long long *scratch, unsigned long long *out,
                             hipStream_t s);
 hipError_t launch_gather_flux(const unsigned long long *acc, const unsigned *leafOfOrig, unsigned n,

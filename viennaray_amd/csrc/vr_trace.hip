@@ -1,8 +1,25 @@
-// vr_trace.hip — the flux-tracing megakernel and its diagnostic siblings.
+// vr_trace.hip — the HIP kernels of the flux tracer (gfx950).
 //
-// One lane = one primary ray followed to termination; the state machine is the
-// reference's TraceKernel::apply() ray loop (include/viennaray/rayTraceKernel.hpp:118-338)
-// with Embree's rtcIntersect1 replaced by closest_hit() (vr_device.hpp).
+// The reference traces rays one by one in index order (rayTraceKernel.hpp:118).
+// Ray i's whole random stream is a pure function of (i, seed), so any order
+// gives the same flux; the GPU path is therefore organised as an HBM-resident
+// RAY STREAM, processed in batches:
+//
+//   gen_kernel      one lane per ray index: per-ray mt19937_64 (lazy, tier 1),
+//                   power-cosine source sample -> 32-byte ray record (+ the next
+//                   VR_NPRE raw engine outputs when the particle keeps going
+//                   after a hit), source-plane cell of the origin, histogram.
+//   scan kernels    exclusive scan of the cell histogram.
+//   scatter_kernel  counting sort of the records by (Morton-ordered) cell, so a
+//                   wavefront's 64 rays start in the same neighbourhood: their
+//                   BVH node / primitive loads hit the same cache lines and their
+//                   traversal loops stay converged.
+//   trace_kernel    persistent wavefronts pull sorted rays; a lane whose ray
+//                   ends pulls the next one (wave-wide compaction by ballot +
+//                   prefix popcount), so bounce chains of different length do
+//                   not idle the wave.  Per segment: closest hit (stackless BVH
+//                   + boundary walls), then the reference's state machine
+//                   (rayTraceKernel.hpp:155-335).
 #include <hip/hip_runtime.h>
 
 #include "vr_device.hpp"
@@ -13,24 +30,23 @@ namespace vr {
 // fixed-point weight: 2^40 per unit (order-independent integer accumulation)
 __device__ __forceinline__ u64 weight_fx(float w) { return (u64)((double)w * 1099511627776.0 + 0.5); }
 
+// ---------------------------------------------------------------------------
+// source sampling (raySourceRandom.hpp:25-116)
+// ---------------------------------------------------------------------------
 template <int D>
 __device__ __forceinline__ void source_sample(const TraceParams &p, Rng &rng, unsigned &t2, V3 &org, V3 &dir) {
-  // raySourceRandom.hpp:50-68 — origin draws first
+  // origin draws first (raySourceRandom.hpp:50-68)
   org = mk(0.f, 0.f, 0.f);
   const float r1 = canon_f32(rng_next(rng, t2));
-  setc(org, p.rayDir, p.minMax ? p.bbHi[p.rayDir] : p.bbLo[p.rayDir]);
-  {
-    const float lo = p.bbLo[p.firstDir], hi = p.bbHi[p.firstDir];
-    setc(org, p.firstDir, lo + (hi - lo) * r1);
-  }
+  setc(org, p.rayDir, p.srcCoord);
+  setc(org, p.firstDir, p.lo1 + (p.hi1 - p.lo1) * r1);
   if (D == 2) {
     setc(org, p.secondDir, 0.f);
   } else {
     const float r2 = canon_f32(rng_next(rng, t2));
-    const float lo = p.bbLo[p.secondDir], hi = p.bbHi[p.secondDir];
-    setc(org, p.secondDir, lo + (hi - lo) * r2);
+    setc(org, p.secondDir, p.lo2 + (p.hi2 - p.lo2) * r2);
   }
-  // raySourceRandom.hpp:70-116 — then the direction draws
+  // then the direction draws (raySourceRandom.hpp:70-116)
   if (!p.useBasis) {
     const float d1 = canon_f32(rng_next(rng, t2));
     const float d2 = canon_f32(rng_next(rng, t2));
@@ -56,7 +72,138 @@ __device__ __forceinline__ void source_sample(const TraceParams &p, Rng &rng, un
   }
 }
 
-// rayUtil.hpp:266-283 + rayReflection.hpp:31-50
+__device__ __forceinline__ unsigned part1by1(unsigned v) {
+  v &= 0x0000FFFFu;
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+// source-plane cell of an origin, Morton-ordered so that consecutive bins are
+// spatial neighbours
+template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p, const V3 &org) {
+  int c1 = (int)((getc(org, p.firstDir) - p.lo1) * p.binInv1);
+  c1 = c1 < 0 ? 0 : (c1 >= p.binT1 ? p.binT1 - 1 : c1);
+  if (D == 2)
+    return (unsigned)c1;
+  int c2 = (int)((getc(org, p.secondDir) - p.lo2) * p.binInv2);
+  c2 = c2 < 0 ? 0 : (c2 >= p.binT2 ? p.binT2 - 1 : c2);
+  return part1by1((unsigned)c1) | (part1by1((unsigned)c2) << 1);
+}
+
+// ---------------------------------------------------------------------------
+// gen_kernel: ray index -> ray record
+// ---------------------------------------------------------------------------
+template <int D, int NPRE>
+__global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
+  __shared__ u64 tape[VR_TAPE * VR_BLOCK];
+  const unsigned tid = threadIdx.x;
+  const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6; // physical wave of this (bounded) grid
+  u64 *scratchLane = p.rngScratch + (size_t)gwave * (312u * 64u) + (tid & 63u);
+  float4 *A = reinterpret_cast<float4 *>(p.genA);
+  float4 *B = reinterpret_cast<float4 *>(p.genB);
+  for (unsigned i = blockIdx.x * VR_BLOCK + tid; i < p.batchCount; i += gridDim.x * VR_BLOCK) {
+    const unsigned long long idx = p.idxList ? p.idxList[i] : p.batchFirst + i;
+    Rng rng;
+    rng_init(rng, tea3((unsigned)idx, p.seed), tape + tid, scratchLane);
+    unsigned t2 = 0;
+    V3 o, d;
+    source_sample<D>(p, rng, t2, o, d);
+    A[i] = make_float4(o.x, o.y, o.z, d.x);
+    B[i] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(rng.k));
+    if (NPRE > 0) {
+#pragma unroll
+      for (int s = 0; s < NPRE; ++s)
+        p.genTape[(size_t)s * p.batchCap + i] = rng_next(rng, t2);
+    }
+    if (p.genBin) {
+      const unsigned b = bin_of<D>(p, o);
+      p.genBin[i] = b;
+      atomicAdd(&p.binHist[b], 1u);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan of the histogram (in place), 2048 elements per block
+// ---------------------------------------------------------------------------
+constexpr unsigned SCAN_PER_THREAD = 8;
+constexpr unsigned SCAN_PER_BLOCK = SCAN_PER_THREAD * VR_BLOCK;
+
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *sh, unsigned &total) {
+  const unsigned tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+  unsigned x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    unsigned y = __shfl_up(x, off, 64);
+    if ((int)lane >= off)
+      x += y;
+  }
+  if (lane == 63)
+    sh[w] = x;
+  __syncthreads();
+  unsigned base = 0;
+  for (unsigned k = 0; k < w; ++k)
+    base += sh[k];
+  total = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return base + x - v;
+}
+
+__global__ __launch_bounds__(VR_BLOCK) void scan_block_kernel(unsigned *data, unsigned n, unsigned *blockSums) {
+  __shared__ unsigned sh[4];
+  const unsigned base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+  unsigned v[SCAN_PER_THREAD];
+  unsigned sum = 0;
+#pragma unroll
+  for (unsigned k = 0; k < SCAN_PER_THREAD; ++k) {
+    v[k] = base + k < n ? data[base + k] : 0u;
+    sum += v[k];
+  }
+  unsigned total;
+  unsigned ex = block_exclusive_scan(sum, sh, total);
+#pragma unroll
+  for (unsigned k = 0; k < SCAN_PER_THREAD; ++k) {
+    if (base + k < n)
+      data[base + k] = ex;
+    ex += v[k];
+  }
+  if (threadIdx.x == 0 && blockSums)
+    blockSums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(VR_BLOCK) void scan_add_kernel(unsigned *data, unsigned n, const unsigned *blockOffsets) {
+  const unsigned off = blockOffsets[blockIdx.x];
+  const unsigned base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+#pragma unroll
+  for (unsigned k = 0; k < SCAN_PER_THREAD; ++k)
+    if (base + k < n)
+      data[base + k] += off;
+}
+
+// ---------------------------------------------------------------------------
+// scatter_kernel: counting sort of the ray records by bin
+// ---------------------------------------------------------------------------
+template <int NPRE> __global__ __launch_bounds__(VR_BLOCK) void scatter_kernel(const TraceParams p) {
+  const unsigned i = blockIdx.x * VR_BLOCK + threadIdx.x;
+  if (i >= p.batchCount)
+    return;
+  const unsigned b = p.genBin[i];
+  const unsigned pos = p.binHist[b] + atomicAdd(&p.binCursor[b], 1u);
+  reinterpret_cast<float4 *>(p.rayA)[pos] = reinterpret_cast<const float4 *>(p.genA)[i];
+  reinterpret_cast<float4 *>(p.rayB)[pos] = reinterpret_cast<const float4 *>(p.genB)[i];
+  if (NPRE > 0) {
+#pragma unroll
+    for (int s = 0; s < NPRE; ++s)
+      p.rayTape[(size_t)s * p.batchCap + pos] = p.genTape[(size_t)s * p.batchCap + i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// reflection sampling (rayUtil.hpp:266-283 + rayReflection.hpp:31-50)
+// ---------------------------------------------------------------------------
 template <int D> __device__ __forceinline__ V3 reflect_diffuse(const V3 &n, Rng &rng, unsigned &t2) {
   float x, y;
   double x2py2;
@@ -74,158 +221,6 @@ template <int D> __device__ __forceinline__ V3 reflect_diffuse(const V3 &n, Rng 
   return r;
 }
 
-struct LaneCounters {
-  unsigned traces, nongeo, geo, boundary, reflections, terminated, tier2;
-};
-
-// One primary ray, start to finish.
-template <int D, int GEO, int PARTICLE>
-__device__ __forceinline__ void trace_ray(const TraceParams &p, unsigned long long idx, u64 *tapeLane,
-                                          u64 *scratchLane, LaneCounters &cnt) {
-  Rng rng;
-  rng_init(rng, tea3((unsigned)idx, p.seed), tapeLane, scratchLane);
-
-  const float initialRayWeight = 1.f;
-  float rayWeight = initialRayWeight;
-  unsigned numReflections = 0, boundaryHits = 0;
-  V3 org, rayDirection;
-  source_sample<D>(p, rng, cnt.tier2, org, rayDirection);
-  V3 dir = project_dir<D>(rayDirection); // what Embree sees (rayUtil.hpp:204-227)
-  const float tnear = 1e-4f;             // rayUtil.hpp:229-231
-
-  const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
-  bool hitFromBack = false;
-  bool reflect;
-  do {
-    reflect = false;
-    HitRec h;
-    closest_hit<GEO>(p, org, dir, tnear, h);
-    ++cnt.traces;
-    if (h.geom < 0) { // rayTraceKernel.hpp:172-176
-      ++cnt.nongeo;
-      break;
-    }
-    const V3 hitPoint = mk(org.x + dir.x * h.t, org.y + dir.y * h.t, org.z + dir.z * h.t);
-
-    if (h.geom == 0) { // boundary, rayTraceKernel.hpp:206-214 + rayBoundary.hpp:29-127
-      if (++boundaryHits > p.maxBoundaryHits) {
-        ++cnt.terminated;
-        break;
-      }
-      const Tri &w = p.wall[h.prim];
-      V3 ng = mk(w.Ng[0], w.Ng[1], w.Ng[2]);
-      reflect = true;
-      if (vdot(dir, ng) > 0.f) { // back side: pass through
-        org = hitPoint;
-        continue;
-      }
-      int bc, axis;
-      bool minWall;
-      if (D == 2 || h.prim <= 3u) {
-        bc = p.bc0;
-        axis = p.firstDir;
-        minWall = h.prim <= 1u;
-      } else {
-        bc = p.bc1;
-        axis = p.secondDir;
-        minWall = h.prim <= 5u;
-      }
-      if (bc == 0) { // REFLECTIVE: rayBoundary.hpp:261-271
-        vnormalize(ng);
-        rayDirection = reflect_specular(rayDirection, ng);
-        dir = project_dir<D>(rayDirection);
-        org = hitPoint;
-      } else if (bc == 1) { // PERIODIC
-        org = hitPoint;
-        setc(org, axis, minWall ? p.bbHi[axis] : p.bbLo[axis]);
-      } else { // IGNORE
-        reflect = false;
-      }
-      continue;
-    }
-
-    // geometry hit
-    V3 geomNormal;
-    if (GEO == 0) {
-      const float4 n4 = prims[2 * h.pos + 1];
-      geomNormal = mk(n4.x, n4.y, n4.z);
-    } else {
-      geomNormal = mk(prims[4 * h.pos + 1].w, prims[4 * h.pos + 2].w, prims[4 * h.pos + 3].w);
-    }
-    const bool backfaceHit = vdot(rayDirection, geomNormal) > 0.f; // rayTraceKernel.hpp:224
-    if (GEO == 0) {
-      if (backfaceHit) {
-        if (hitFromBack) {
-          ++cnt.terminated;
-          break;
-        }
-        hitFromBack = true;
-        reflect = true;
-        org = hitPoint;
-        continue;
-      }
-    } else if (backfaceHit) {
-      ++cnt.terminated;
-      break;
-    }
-
-    ++cnt.geo;
-    const u64 wfx = weight_fx(rayWeight);
-    atomicAdd(&p.fluxAcc[h.pos], wfx); // surfaceCollision, rayParticle.hpp:148-156
-    if (GEO == 0) {
-      // every overlapping neighbour disk is credited the full weight
-      // (rayTraceKernel.hpp:271-300)
-      const unsigned b = p.nbOff[h.pos], e = p.nbOff[h.pos + 1];
-      for (unsigned j = b; j < e; ++j) {
-        const unsigned q = p.nbIds[j];
-        const float4 c4 = prims[2 * q];
-        const float4 n4 = prims[2 * q + 1];
-        if (local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)))
-          atomicAdd(&p.fluxAcc[q], wfx);
-      }
-    }
-
-    // surfaceReflection is evaluated (and draws) even when sticking == 1 (Q2)
-    V3 newDir;
-    if (PARTICLE == 0)
-      newDir = reflect_diffuse<D>(geomNormal, rng, cnt.tier2);
-    else
-      newDir = reflect_specular(rayDirection, geomNormal);
-    const float sticking = p.primSticking ? p.primSticking[h.pos] : p.sticking;
-
-    rayWeight -= rayWeight * sticking; // rayTraceKernel.hpp:316-319
-    if (rayWeight <= 0.f)
-      break;
-    if (++numReflections > p.maxReflections) {
-      ++cnt.terminated;
-      break;
-    }
-    // rejectionControl, rayTraceKernel.hpp:435-460
-    {
-      const float lowerThreshold = (float)(0.1 * (double)initialRayWeight);
-      const float renewWeight = (float)(0.3 * (double)initialRayWeight);
-      if (rayWeight >= lowerThreshold) {
-        reflect = true;
-      } else {
-        const double killProbability = 1.0 - (double)(rayWeight / renewWeight);
-        if (canon_f64(rng_next(rng, cnt.tier2)) < killProbability) {
-          reflect = false;
-        } else {
-          rayWeight = renewWeight;
-          reflect = true;
-        }
-      }
-    }
-    if (!reflect)
-      break;
-    rayDirection = newDir;
-    org = hitPoint;
-    dir = project_dir<D>(rayDirection);
-  } while (reflect);
-  cnt.boundary += boundaryHits;
-  cnt.reflections += numReflections;
-}
-
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
   unsigned long long s = v;
 #pragma unroll
@@ -234,32 +229,239 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
   return s;
 }
 
-template <int D, int GEO, int PARTICLE>
+__device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xFFFFFFFFull));
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------
+// trace_kernel
+//   ABSORB: every hit absorbs the whole weight (sticking >= 1 everywhere), so
+//   nothing after the first surface hit is observable and the reflection /
+//   roulette code (and its RNG) is compiled out.
+// ---------------------------------------------------------------------------
+template <int D, int GEO, int PARTICLE, bool ABSORB>
 __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
-  __shared__ u64 tape[VR_TAPE * VR_BLOCK];
-  __shared__ unsigned long long chunkBase;
+  constexpr int NPRE = ABSORB ? 0 : VR_NPRE;
+  __shared__ float wallS[96];
+  __shared__ u64 tape[NPRE > 0 ? NPRE * VR_BLOCK : 1];
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
-  u64 *tapeLane = tape + tid;
-  u64 *scratchLane = p.rngScratch + (size_t)gwave * (312u * 64u) + lane;
-  LaneCounters cnt = {0, 0, 0, 0, 0, 0, 0};
+  if (tid < 96)
+    wallS[tid] = p.wallTable[tid];
+  __syncthreads();
 
-  const unsigned long long total = p.rayEnd - p.rayFirst;
+  const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
+  const float4 *__restrict__ rayA = reinterpret_cast<const float4 *>(p.rayA);
+  const float4 *__restrict__ rayB = reinterpret_cast<const float4 *>(p.rayB);
+  const float tnear = 1e-4f; // rayUtil.hpp:229-231
+
+  // per-lane ray state
+  bool active = false;
+  V3 org = mk(0, 0, 0), rayDirection = mk(0, 0, 1), dir = mk(0, 0, 1);
+  float rayWeight = 0.f;
+  unsigned numReflections = 0, boundaryHits = 0;
+  bool hitFromBack = false;
+  Rng rng;
+  rng.tape = tape + tid;
+  rng.scratch = p.rngScratch + (size_t)gwave * (312u * 64u) + lane;
+  rng.nTape = NPRE;
+  rng.k = rng.k0 = 0;
+  rng.pos = 0xFFFFFFFFu;
+  rng.seed = 0;
+  // counters
+  unsigned cTraces = 0, cNongeo = 0, cGeo = 0, cBoundary = 0, cRefl = 0, cTerm = 0, cTier2 = 0;
+  // wave-uniform work span
+  unsigned waveNext = 0, waveEnd = 0;
+  bool exhausted = false;
+
   for (;;) {
-    if (tid == 0)
-      chunkBase = atomicAdd(p.workCounter, (unsigned long long)p.chunk);
-    __syncthreads();
-    const unsigned long long base = chunkBase;
-    __syncthreads();
-    if (base >= total)
+    // keep the compiler from hoisting the (loop-invariant) LDS wall table into
+    // ~100 registers: occupancy matters more than 24 ds_reads per segment
+    asm volatile("" ::: "memory");
+    // ---- wave-wide compaction / restart: idle lanes pull the next sorted rays ----
+    for (int rep = 0; rep < 2; ++rep) {
+      const unsigned long long idle = __ballot(!active);
+      if (!idle)
+        break;
+      if (waveNext == waveEnd) {
+        if (exhausted)
+          break;
+        unsigned long long s = 0;
+        if (lane == 0)
+          s = atomicAdd(p.workCounter, (unsigned long long)p.chunk);
+        s = bcast64(s);
+        if (s >= p.batchCount) {
+          exhausted = true;
+          break;
+        }
+        waveNext = (unsigned)s;
+        waveEnd = (unsigned)((s + p.chunk < p.batchCount) ? s + p.chunk : p.batchCount);
+      }
+      const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
+      const unsigned avail = waveEnd - waveNext;
+      if (!active && rank < avail) {
+        const unsigned j = waveNext + rank;
+        const float4 a = rayA[j];
+        const float4 b = rayB[j];
+        org = mk(a.x, a.y, a.z);
+        rayDirection = mk(a.w, b.x, b.y);
+        dir = project_dir<D>(rayDirection); // what Embree sees (rayUtil.hpp:204-227)
+        rayWeight = 1.f;                    // Source::getInitialRayWeight
+        numReflections = 0;
+        boundaryHits = 0;
+        hitFromBack = false;
+        active = true;
+        if (!ABSORB) {
+          const unsigned idxOff = __float_as_uint(b.z);
+          rng.seed = tea3((unsigned)(p.batchFirst + idxOff), p.seed);
+          rng.k = rng.k0 = __float_as_uint(b.w);
+          rng.pos = 0xFFFFFFFFu;
+#pragma unroll
+          for (int s = 0; s < NPRE; ++s)
+            tape[s * VR_BLOCK + tid] = p.rayTape[(size_t)s * p.batchCap + j];
+        }
+      }
+      const unsigned nIdle = __popcll(idle);
+      waveNext += nIdle < avail ? nIdle : avail;
+    }
+    if (!__ballot(active))
       break;
-    const unsigned long long end = (base + p.chunk < total) ? base + p.chunk : total;
-    for (unsigned long long r = base + tid; r < end; r += VR_BLOCK)
-      trace_ray<D, GEO, PARTICLE>(p, p.rayFirst + r, tapeLane, scratchLane, cnt);
+
+    if (active) {
+      // ---- one trace segment (rayTraceKernel.hpp:155-335) ----
+      HitRec h;
+      closest_hit<GEO>(p, wallS, org, dir, tnear, h);
+      ++cTraces;
+      if (h.geom < 0) { // miss, :172-176
+        ++cNongeo;
+        active = false;
+      } else {
+        const V3 hitPoint = mk(org.x + dir.x * h.t, org.y + dir.y * h.t, org.z + dir.z * h.t);
+        if (h.geom == 0) { // boundary, :206-214 + rayBoundary.hpp:29-127
+          if (++boundaryHits > p.maxBoundaryHits) {
+            ++cTerm;
+            active = false;
+          } else {
+            const float *w = wallS + 12 * h.prim;
+            V3 ng = mk(w[9], w[10], w[11]);
+            if (vdot(dir, ng) > 0.f) { // back side: pass through
+              org = hitPoint;
+            } else {
+              int bc, axis;
+              bool minWall;
+              if (D == 2 || h.prim <= 3u) {
+                bc = p.bc0;
+                axis = p.firstDir;
+                minWall = h.prim <= 1u;
+              } else {
+                bc = p.bc1;
+                axis = p.secondDir;
+                minWall = h.prim <= 5u;
+              }
+              if (bc == 0) { // REFLECTIVE, rayBoundary.hpp:261-271
+                vnormalize(ng);
+                rayDirection = reflect_specular(rayDirection, ng);
+                dir = project_dir<D>(rayDirection);
+                org = hitPoint;
+              } else if (bc == 1) { // PERIODIC: wrap to the opposite face
+                org = hitPoint;
+                const bool first = (D == 2 || h.prim <= 3u);
+                const float wrapTo = first ? (minWall ? p.hi1 : p.lo1) : (minWall ? p.hi2 : p.lo2);
+                setc(org, axis, wrapTo);
+              } else { // IGNORE
+                active = false;
+              }
+            }
+          }
+        } else {
+          // geometry hit
+          V3 geomNormal;
+          if (GEO == 0) {
+            const float4 n4 = prims[2 * h.pos + 1];
+            geomNormal = mk(n4.x, n4.y, n4.z);
+          } else {
+            geomNormal = mk(prims[4 * h.pos + 1].w, prims[4 * h.pos + 2].w, prims[4 * h.pos + 3].w);
+          }
+          const bool backfaceHit = vdot(rayDirection, geomNormal) > 0.f; // :224
+          if (backfaceHit) {
+            if (GEO == 0 && !hitFromBack) { // first back hit of a disk: let through, :235-240
+              hitFromBack = true;
+              org = hitPoint;
+            } else { // :229-233, :243-248
+              ++cTerm;
+              active = false;
+            }
+          } else {
+            ++cGeo;
+            const u64 wfx = weight_fx(rayWeight);
+            atomicAdd(&p.fluxAcc[h.pos], wfx); // surfaceCollision, rayParticle.hpp:148-156
+            if (GEO == 0) {
+              // every overlapping neighbour disk is credited the full weight (:271-300)
+              const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
+              for (unsigned j = nb; j < ne; ++j) {
+                const unsigned q = p.nbIds[j];
+                const float4 c4 = prims[2 * q];
+                const float4 n4 = prims[2 * q + 1];
+                if (local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)))
+                  atomicAdd(&p.fluxAcc[q], wfx);
+              }
+            }
+            if (ABSORB) {
+              // sticking >= 1: weight drops to <= 0 (:316-319); the reflection draws
+              // the reference makes before that test (Q2) are not observable.
+              active = false;
+            } else {
+              const float sticking = p.primSticking ? p.primSticking[h.pos] : p.sticking;
+              const float wAfter = rayWeight - rayWeight * sticking;
+              if (wAfter <= 0.f) {
+                active = false; // as above: the pending draws die with the ray
+              } else {
+                // surfaceReflection, rayParticle.hpp:137-146 / 178-187
+                V3 newDir;
+                if (PARTICLE == 0)
+                  newDir = reflect_diffuse<D>(geomNormal, rng, cTier2);
+                else
+                  newDir = reflect_specular(rayDirection, geomNormal);
+                rayWeight = wAfter;
+                if (++numReflections > p.maxReflections) { // :320-324
+                  ++cTerm;
+                  active = false;
+                } else {
+                  // rejectionControl, :435-460
+                  const float lowerThreshold = (float)(0.1 * 1.0);
+                  const float renewWeight = (float)(0.3 * 1.0);
+                  bool reflect = true;
+                  if (!(rayWeight >= lowerThreshold)) {
+                    const double killProbability = 1.0 - (double)(rayWeight / renewWeight);
+                    if (canon_f64(rng_next(rng, cTier2)) < killProbability)
+                      reflect = false;
+                    else
+                      rayWeight = renewWeight;
+                  }
+                  if (!reflect) {
+                    active = false;
+                  } else {
+                    rayDirection = newDir;
+                    org = hitPoint;
+                    dir = project_dir<D>(rayDirection);
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      if (!active) {
+        cBoundary += boundaryHits;
+        cRefl += numReflections;
+      }
+    }
   }
 
-  const unsigned vals[8] = {cnt.traces, cnt.nongeo, cnt.geo, 0u, cnt.boundary, cnt.reflections, cnt.terminated, cnt.tier2};
+  const unsigned vals[8] = {cTraces, cNongeo, cGeo, 0u, cBoundary, cRefl, cTerm, cTier2};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const unsigned long long s = wave_sum(vals[i]);
@@ -271,23 +473,100 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
 // ---------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------
-template <int D, int GEO, int PARTICLE>
-static hipError_t launch_t(const TraceParams &p, unsigned grid, hipStream_t s) {
-  hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+hipError_t launch_gen(const TraceParams &p, int D, bool withTape, unsigned maxBlocks, hipStream_t s) {
+  unsigned grid = (p.batchCount + VR_BLOCK - 1) / VR_BLOCK;
+  if (grid == 0)
+    return hipSuccess;
+  if (grid > maxBlocks)
+    grid = maxBlocks; // grid-stride; bounds the tier-2 slabs to grid waves
+  if (D == 2) {
+    if (withTape)
+      hipLaunchKernelGGL((gen_kernel<2, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+    else
+      hipLaunchKernelGGL((gen_kernel<2, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  } else {
+    if (withTape)
+      hipLaunchKernelGGL((gen_kernel<3, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+    else
+      hipLaunchKernelGGL((gen_kernel<3, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  }
   return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, unsigned grid, hipStream_t s) {
+hipError_t launch_scan(unsigned *data, unsigned n, unsigned *tmp /* >= 2 * ceil(n/2048) + 2 */, hipStream_t s) {
+  const unsigned blocks = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+  if (blocks <= 1) {
+    hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(VR_BLOCK), 0, s, data, n, (unsigned *)nullptr);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(scan_block_kernel, dim3(blocks), dim3(VR_BLOCK), 0, s, data, n, tmp);
+  hipError_t e = launch_scan(tmp, blocks, tmp + blocks, s);
+  if (e != hipSuccess)
+    return e;
+  hipLaunchKernelGGL(scan_add_kernel, dim3(blocks), dim3(VR_BLOCK), 0, s, data, n, tmp);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter(const TraceParams &p, bool withTape, hipStream_t s) {
+  const unsigned grid = (p.batchCount + VR_BLOCK - 1) / VR_BLOCK;
+  if (grid == 0)
+    return hipSuccess;
+  if (withTape)
+    hipLaunchKernelGGL((scatter_kernel<VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  else
+    hipLaunchKernelGGL((scatter_kernel<0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  return hipGetLastError();
+}
+
+template <int D, int GEO, int PARTICLE>
+static hipError_t launch_trace_t(const TraceParams &p, bool absorb, unsigned grid, hipStream_t s) {
+  if (absorb)
+    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  else
+    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, bool absorb, unsigned grid,
+                        hipStream_t s) {
+  if (absorb)
+    particle = 0; // the reflection model is unobservable: one instantiation serves both
   const int key = (D == 2 ? 0 : 4) | (geo ? 2 : 0) | (particle ? 1 : 0);
   switch (key) {
-  case 0: return launch_t<2, 0, 0>(p, grid, s);
-  case 1: return launch_t<2, 0, 1>(p, grid, s);
-  case 2: return launch_t<2, 1, 0>(p, grid, s);
-  case 3: return launch_t<2, 1, 1>(p, grid, s);
-  case 4: return launch_t<3, 0, 0>(p, grid, s);
-  case 5: return launch_t<3, 0, 1>(p, grid, s);
-  case 6: return launch_t<3, 1, 0>(p, grid, s);
-  default: return launch_t<3, 1, 1>(p, grid, s);
+  case 0: return launch_trace_t<2, 0, 0>(p, absorb, grid, s);
+  case 1: return launch_trace_t<2, 0, 1>(p, absorb, grid, s);
+  case 2: return launch_trace_t<2, 1, 0>(p, absorb, grid, s);
+  case 3: return launch_trace_t<2, 1, 1>(p, absorb, grid, s);
+  case 4: return launch_trace_t<3, 0, 0>(p, absorb, grid, s);
+  case 5: return launch_trace_t<3, 0, 1>(p, absorb, grid, s);
+  case 6: return launch_trace_t<3, 1, 0>(p, absorb, grid, s);
+  default: return launch_trace_t<3, 1, 1>(p, absorb, grid, s);
+  }
+}
+
+template <int D, int GEO, int PARTICLE> static int occ_t(bool absorb) {
+  int nb = 0;
+  hipError_t e;
+  if (absorb)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, true>, VR_BLOCK, 0);
+  else
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, false>, VR_BLOCK, 0);
+  return e == hipSuccess ? nb : 2;
+}
+
+int trace_blocks_per_cu(int D, int geo, int particle, bool absorb) {
+  if (absorb)
+    particle = 0;
+  const int key = (D == 2 ? 0 : 4) | (geo ? 2 : 0) | (particle ? 1 : 0);
+  switch (key) {
+  case 0: return occ_t<2, 0, 0>(absorb);
+  case 1: return occ_t<2, 0, 1>(absorb);
+  case 2: return occ_t<2, 1, 0>(absorb);
+  case 3: return occ_t<2, 1, 1>(absorb);
+  case 4: return occ_t<3, 0, 0>(absorb);
+  case 5: return occ_t<3, 0, 1>(absorb);
+  case 6: return occ_t<3, 1, 0>(absorb);
+  default: return occ_t<3, 1, 1>(absorb);
   }
 }
 
@@ -295,12 +574,16 @@ hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, unsi
 template <int GEO>
 __global__ void debug_intersect_kernel(const TraceParams p, const float *org, const float *dir,
                                        const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t) {
+  __shared__ float wallS[96];
+  for (unsigned k = threadIdx.x; k < 96; k += blockDim.x)
+    wallS[k] = p.wallTable[k];
+  __syncthreads();
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n)
     return;
   HitRec h;
-  closest_hit<GEO>(p, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]),
-                   tnear[i], h);
+  closest_hit<GEO>(p, wallS, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]),
+                   mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), tnear[i], h);
   geomID[i] = h.geom;
   primID[i] = h.prim;
   t[i] = h.t;
@@ -314,38 +597,6 @@ hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *or
     hipLaunchKernelGGL((debug_intersect_kernel<0>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t);
   else
     hipLaunchKernelGGL((debug_intersect_kernel<1>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t);
-  return hipGetLastError();
-}
-
-template <int D>
-__global__ __launch_bounds__(VR_BLOCK) void debug_source_kernel(const TraceParams p, const unsigned long long *idx,
-                                                                 unsigned n, float *org, float *dir) {
-  __shared__ u64 tape[VR_TAPE * VR_BLOCK];
-  const unsigned tid = threadIdx.x;
-  const unsigned i = blockIdx.x * VR_BLOCK + tid;
-  if (i >= n)
-    return;
-  const unsigned gwave = i >> 6;
-  Rng rng;
-  rng_init(rng, tea3((unsigned)idx[i], p.seed), tape + tid, p.rngScratch + (size_t)gwave * (312u * 64u) + (tid & 63u));
-  unsigned t2 = 0;
-  V3 o, d;
-  source_sample<D>(p, rng, t2, o, d);
-  org[3 * i] = o.x;
-  org[3 * i + 1] = o.y;
-  org[3 * i + 2] = o.z;
-  dir[3 * i] = d.x;
-  dir[3 * i + 1] = d.y;
-  dir[3 * i + 2] = d.z;
-}
-
-hipError_t launch_debug_source(const TraceParams &p, int D, const unsigned long long *idx, unsigned n, float *org,
-                               float *dir, hipStream_t s) {
-  const unsigned grid = (n + VR_BLOCK - 1) / VR_BLOCK;
-  if (D == 2)
-    hipLaunchKernelGGL((debug_source_kernel<2>), dim3(grid), dim3(VR_BLOCK), 0, s, p, idx, n, org, dir);
-  else
-    hipLaunchKernelGGL((debug_source_kernel<3>), dim3(grid), dim3(VR_BLOCK), 0, s, p, idx, n, org, dir);
   return hipGetLastError();
 }
 

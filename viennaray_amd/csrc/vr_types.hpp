@@ -26,32 +26,57 @@ struct Tri {       // boundary wall triangle, Embree's precomputed form
   float v0[3], e1[3], e2[3], Ng[3];
 };
 
-// number of per-ray RNG outputs kept in the LDS tape (tier 1)
+// Ray stream record (HBM-resident, sorted by source-plane cell before tracing):
+//   A = {org.x, org.y, org.z, dir.x}   B = {dir.y, dir.z, bits(idx - batchFirst), bits(k)}
+//   k = number of engine outputs the source sampling consumed
+//   tape[s][i] (only for particles that keep going after a hit): raw engine
+//   outputs k .. k+VR_NPRE-1 of ray i, structure-of-arrays by slot
+constexpr int VR_NPRE = 8;
+
+// number of per-ray RNG outputs the generator keeps in its LDS tape (tier 1)
 constexpr int VR_TAPE = 16;
 constexpr int VR_BLOCK = 256;
 
 struct TraceParams {
+  // geometry (device pointers)
   const float *nodes;         // float4 pairs
   const float *prims;         // float4 records
   const uint32_t *nbOff;      // [numPrims+1], disk neighbourhood CSR (leaf order)
   const uint32_t *nbIds;      // leaf positions
   const float *primSticking;  // optional [numPrims] (leaf order) or nullptr
+  const float *wallTable;     // 8 x {v0, e1, e2, Ng} = 96 floats
   unsigned long long *fluxAcc;   // [numPrims] leaf order, fixed point 2^-40
   unsigned long long *counters;  // [8]
   unsigned long long *workCounter;
-  unsigned long long *rngScratch; // [gridWaves][312][64]
-  uint64_t rayFirst, rayEnd;  // global ray index range of this launch
+  unsigned long long *rngScratch; // [waves][312][64]
+  // ray stream of the current batch
+  float *genA, *genB;             // unsorted, float4 per ray
+  unsigned long long *genTape;    // [VR_NPRE][batchCap] or nullptr
+  uint32_t *genBin;               // bin of each unsorted ray
+  float *rayA, *rayB;             // sorted
+  unsigned long long *rayTape;
+  uint32_t *binHist;              // [numBins] counts -> exclusive starts
+  uint32_t *binCursor;            // [numBins]
+  const unsigned long long *idxList; // diagnostics: explicit ray indices (or nullptr)
+  uint64_t batchFirst;            // global ray index of the batch's ray 0
+  uint32_t batchCount;            // rays in this batch
+  uint32_t batchCap;              // slot stride of the tapes
+  uint32_t numBins;
   uint32_t seed;
   uint32_t numPrims;
   uint32_t maxReflections, maxBoundaryHits;
-  uint32_t chunk;             // rays per work-queue grab (multiple of 256)
+  uint32_t chunk;                 // rays per work-queue grab of one wave
   int32_t rayDir, firstDir, secondDir, minMax;
   float posNeg, ee, sticking;
   int32_t bc0, bc1;
   int32_t useBasis;
-  float basis[9];             // [b][component]
-  float bbLo[3], bbHi[3];     // adjusted bounding box
-  Tri wall[8];
+  float basis[9];                 // [b][component]
+  // adjusted bounding box, as scalars (no dynamic indexing of kernel arguments)
+  float srcCoord;                 // origin[rayDir]
+  float lo1, hi1, lo2, hi2;       // extents along firstDir / secondDir
+  // source-plane binning
+  float binInv1, binInv2;         // cells per unit length
+  int32_t binT1, binT2;           // cells per axis
 };
 
 // counters[] slots
