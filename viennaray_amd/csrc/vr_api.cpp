@@ -586,8 +586,12 @@ int vr_apply_prepare(vr_context *c) {
   p.hi1 = c->bbHi[c->ts[1]];
   p.lo2 = c->bbLo[c->ts[2]];
   p.hi2 = c->bbHi[c->ts[2]];
-  p.binInv1 = (p.hi1 > p.lo1) ? (float)p.binT1 / (p.hi1 - p.lo1) : 0.f;
-  p.binInv2 = (p.hi2 > p.lo2) ? (float)p.binT2 / (p.hi2 - p.lo2) : 0.f;
+  p.farCoord = c->ts[3] ? c->geo.minC[c->ts[0]] : c->geo.maxC[c->ts[0]];
+  p.invExt1 = (p.hi1 > p.lo1) ? 1.f / (p.hi1 - p.lo1) : 0.f;
+  p.invExt2 = (p.hi2 > p.lo2) ? 1.f / (p.hi2 - p.lo2) : 0.f;
+  p.debugFlags = 0;
+  if (const char *e = std::getenv("VR_DEBUG_FLAGS"))
+    p.debugFlags = (uint32_t)std::atoi(e);
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (redoConfig)
     c->buildSeconds = secs; // a cheap re-prepare (new seed / ray range only) keeps the last build time

@@ -81,14 +81,34 @@ __device__ __forceinline__ unsigned part1by1(unsigned v) {
   return v;
 }
 
-// source-plane cell of an origin, Morton-ordered so that consecutive bins are
-// spatial neighbours
-template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p, const V3 &org) {
-  int c1 = (int)((getc(org, p.firstDir) - p.lo1) * p.binInv1);
+// Sort key of a ray: the cell in which it crosses the FAR plane of the geometry's
+// bounding box (the plane opposite the source), folded back into the domain the
+// way the side walls would (periodic wrap / mirror).  For surface-like
+// geometry that is where the ray ends up and where the BVH is deepest, so the 64
+// rays of a wavefront walk (almost) the same nodes and leaves.  Cells are
+// Morton-ordered so consecutive bins are spatial neighbours.  The key only
+// orders the work; it has no influence on any result.
+__device__ __forceinline__ float fold_unit(float u, int bc) {
+  if (bc == 1) // periodic
+    return u - floorf(u);
+  if (bc == 0) { // reflective: mirror fold with period 2
+    float v = u - 2.f * floorf(0.5f * u);
+    return v > 1.f ? 2.f - v : v;
+  }
+  return u; // ignore: clamped below
+}
+
+template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p, const V3 &org, const V3 &dir) {
+  const float dr = getc(dir, p.rayDir);
+  float t = (p.farCoord - p.srcCoord) / (fabsf(dr) > 1e-6f ? dr : copysignf(1e-6f, dr == 0.f ? -p.posNeg : dr));
+  t = (p.debugFlags & 2u) ? 0.f : (t > 0.f ? t : 0.f); // flag 2: key on the origin instead
+  const float u1 = fold_unit((getc(org, p.firstDir) + getc(dir, p.firstDir) * t - p.lo1) * p.invExt1, p.bc0);
+  int c1 = (int)(u1 * (float)p.binT1);
   c1 = c1 < 0 ? 0 : (c1 >= p.binT1 ? p.binT1 - 1 : c1);
   if (D == 2)
     return (unsigned)c1;
-  int c2 = (int)((getc(org, p.secondDir) - p.lo2) * p.binInv2);
+  const float u2 = fold_unit((getc(org, p.secondDir) + getc(dir, p.secondDir) * t - p.lo2) * p.invExt2, p.bc1);
+  int c2 = (int)(u2 * (float)p.binT2);
   c2 = c2 < 0 ? 0 : (c2 >= p.binT2 ? p.binT2 - 1 : c2);
   return part1by1((unsigned)c1) | (part1by1((unsigned)c2) << 1);
 }
@@ -119,7 +139,7 @@ __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
         p.genTape[(size_t)s * p.batchCap + i] = rng_next(rng, t2);
     }
     if (p.genBin) {
-      const unsigned b = bin_of<D>(p, o);
+      const unsigned b = bin_of<D>(p, o, project_dir<D>(d));
       p.genBin[i] = b;
       atomicAdd(&p.binHist[b], 1u);
     }
@@ -397,7 +417,8 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
           } else {
             ++cGeo;
             const u64 wfx = weight_fx(rayWeight);
-            atomicAdd(&p.fluxAcc[h.pos], wfx); // surfaceCollision, rayParticle.hpp:148-156
+            if (!(p.debugFlags & 1u))
+              atomicAdd(&p.fluxAcc[h.pos], wfx); // surfaceCollision, rayParticle.hpp:148-156
             if (GEO == 0) {
               // every overlapping neighbour disk is credited the full weight (:271-300)
               const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
                 const unsigned q = p.nbIds[j];
                 const float4 c4 = prims[2 * q];
                 const float4 n4 = prims[2 * q + 1];
-                if (local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)))
+                if (local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u))
                   atomicAdd(&p.fluxAcc[q], wfx);
               }
             }

@@ -74,9 +74,11 @@ struct TraceParams {
   // adjusted bounding box, as scalars (no dynamic indexing of kernel arguments)
   float srcCoord;                 // origin[rayDir]
   float lo1, hi1, lo2, hi2;       // extents along firstDir / secondDir
-  // source-plane binning
-  float binInv1, binInv2;         // cells per unit length
+  // sort-key binning (far-plane crossing cell)
+  float farCoord;                 // geometry bbox face opposite the source, on rayDir
+  float invExt1, invExt2;         // 1 / (hi - lo) along firstDir / secondDir (0 if degenerate)
   int32_t binT1, binT2;           // cells per axis
+  uint32_t debugFlags;            // VR_DEBUG_FLAGS (timing experiments; 0 in production)
 };
 
 // counters[] slots
