@@ -104,10 +104,8 @@ def main():
     tr.setRngSeed(seed)
     total_rays = args.rays * world
     tr.setNumberOfRaysFixed(total_rays)
-    tr.setRayRange(rank * args.rays, args.rays)  # global ray indices
-    acc = torch.zeros(N, dtype=torch.int64, device=f"cuda:{local_rank}")
-    tr.bindFluxAccumulators(acc.data_ptr(), N)
-    counters = torch.zeros(8, dtype=torch.int64, device=f"cuda:{local_rank}")
+    from viennaray_amd import distributed as vd
+    shard = vd.GpuShard(tr, f"cuda:{local_rank}")  # binds a torch int64 accumulator tensor
 
     t0 = time.perf_counter()
     tr.applyPrepare()  # bbox, walls, areas, LBVH, uploads: geometry resident in HBM
@@ -119,18 +117,11 @@ def main():
     geo = []
 
     def step():
-        tr.setRunNumber(1)  # every step traces the same seeded stream (kernel seed 12346)
-        tr.applyPrepare()
-        tr.applyLaunch()
-        tr.applyFinish(collect=False)
-        info = tr.getRayTraceInfo()
-        if distributed:
-            counters[:] = torch.tensor([info.totalRaysTraced, info.nonGeometryHits, info.geometryHits,
-                                        info.particleHits, info.boundaryHits, info.reflections,
-                                        info.raysTerminated, 0], dtype=torch.int64)
-            dist.all_reduce(acc)       # RCCL sum of the int64 flux accumulators (exact)
-            dist.all_reduce(counters)
-        return info
+        # rank r traces global ray indices [r*rays, (r+1)*rays), then ONE
+        # RCCL all-reduce of the int64 flux accumulators (+ the 7 counters).  Every
+        # step traces the same seeded stream (runNumber 1 -> kernel seed 12346).
+        acc, counters = vd.distributed_apply(shard, total_rays, rank, world, run_number=1)
+        return shard.last_info, counters
 
     def sync_all():
         if distributed:
@@ -142,10 +133,10 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        info = step()
+        info, _ = step()
         kernel_ms.append(info.timeTrace * 1e3)
         trace_ms.append(info.timeTraceKernel * 1e3)
-        segs.append(int(info.totalRaysTraced))
+        segs.append(int(info.totalRaysTraced))   # this rank's share
         geo.append(int(info.geometryHits))
     sync_all()
     elapsed = time.perf_counter() - t0

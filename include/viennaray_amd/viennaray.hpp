@@ -1,0 +1,466 @@
+// viennaray.hpp — header-only C++ façade with the reference's class, method and
+// enum names for the accelerated path, implemented on the C ABI of
+// include/viennaray_amd.h (link with libviennaray_amd.so).
+//
+// It mirrors, for the path Trace<T,D>::apply() covers:
+//   viennaray::Trace / TraceDisk / TraceTriangle   (rayTrace.hpp:15-180,
+//       rayTraceDisk.hpp:13-224, rayTraceTriangle.hpp:13-154)
+//   viennaray::DiffuseParticle / SpecularParticle  (rayParticle.hpp:126-204)
+//   viennaray::TracingData                         (rayTracingData.hpp:16-219)
+//   viennaray::TraceInfo, BoundaryCondition, TraceDirection, NormalizationType
+//   viennaray::DiskMesh / TriangleMesh             (rayMesh.hpp:82-131)
+//   rayInternal::readGridFromFile / readMeshFromFile / createPlaneGrid / writeVTK
+// so a reference example builds by pointing its include path here (see
+// examples/ and INTEGRATION.md).  The device computes in float; NumericType
+// double is accepted and converted at the boundary, as the reference does when
+// it fills Embree's float buffers (rayGeometryDisk.hpp:137-175).
+//
+// Not covered (out of scope): user-defined AbstractParticle /
+// Source subclasses — per-hit host callbacks cannot run inside a HIP kernel.
+// setParticleType() accepts the two built-in particles only.
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <memory>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "../viennaray_amd.h"
+
+namespace viennacore {
+template <class T, size_t D> using VectorType = std::array<T, D>;
+template <class T> using Vec2D = std::array<T, 2>;
+template <class T> using Vec3D = std::array<T, 3>;
+using Vec3Df = Vec3D<float>;
+
+struct Timer {
+  std::chrono::steady_clock::time_point t0;
+  long long currentDuration = 0; // ns
+  void start() { t0 = std::chrono::steady_clock::now(); }
+  void finish() {
+    currentDuration = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
+} // namespace viennacore
+
+namespace viennaray {
+using namespace viennacore;
+
+enum class BoundaryCondition : unsigned { REFLECTIVE_BOUNDARY = 0, PERIODIC_BOUNDARY = 1, IGNORE_BOUNDARY = 2 };
+enum class TraceDirection : unsigned { POS_X = 0, NEG_X = 1, POS_Y = 2, NEG_Y = 3, POS_Z = 4, NEG_Z = 5 };
+enum class NormalizationType : unsigned { SOURCE = 0, MAX = 1 };
+enum class TracingDataMergeEnum : unsigned { SUM = 0, APPEND = 1, AVERAGE = 2 };
+
+struct TraceInfo {
+  size_t numRays = 0;
+  size_t totalRaysTraced = 0;
+  size_t nonGeometryHits = 0;
+  size_t geometryHits = 0;
+  size_t particleHits = 0;
+  size_t boundaryHits = 0;
+  size_t reflections = 0;
+  double time = 0.0;
+  bool warning = false;
+  bool error = false;
+};
+
+// ---- meshes (rayMesh.hpp) -------------------------------------------------------
+struct DiskMesh {
+  DiskMesh() = default;
+  DiskMesh(const std::vector<Vec3Df> &pts, const std::vector<Vec3Df> &nms, float delta)
+      : nodes(pts), normals(nms), gridDelta(delta) {}
+  std::vector<Vec3Df> nodes;
+  std::vector<Vec3Df> normals;
+  float gridDelta = 0.f;
+};
+
+struct TriangleMesh {
+  TriangleMesh() = default;
+  TriangleMesh(std::vector<Vec3Df> const &pts, std::vector<Vec3D<unsigned>> const &tris, float delta)
+      : nodes(pts), triangles(tris), gridDelta(delta) {}
+  std::vector<Vec3Df> nodes;
+  std::vector<Vec3D<unsigned>> triangles;
+  float gridDelta = 0.f;
+};
+
+// ---- TracingData (vector data part) ------------------------------------------------
+template <typename NumericType> class TracingData {
+  std::vector<std::vector<NumericType>> vectorData_;
+  std::vector<std::string> vectorDataLabels_;
+  std::vector<TracingDataMergeEnum> vectorDataMerge_;
+
+public:
+  void setNumberOfVectorData(int size) {
+    vectorData_.clear();
+    vectorData_.resize(size);
+    vectorDataMerge_.resize(size, TracingDataMergeEnum::SUM);
+    vectorDataLabels_.resize(size, "vectorData");
+  }
+  void setVectorData(int num, std::vector<NumericType> &&v, std::string label = "vectorData") {
+    vectorData_[num] = std::move(v);
+    vectorDataLabels_[num] = std::move(label);
+  }
+  void setVectorData(int num, size_t size, NumericType value, std::string label = "vectorData") {
+    vectorData_[num].assign(size, value);
+    vectorDataLabels_[num] = std::move(label);
+  }
+  [[nodiscard]] std::vector<NumericType> &getVectorData(int i) { return vectorData_[i]; }
+  [[nodiscard]] std::vector<NumericType> &getVectorData(const std::string &label) {
+    return vectorData_[getVectorDataIndex(label)];
+  }
+  [[nodiscard]] std::vector<std::vector<NumericType>> &getVectorData() { return vectorData_; }
+  [[nodiscard]] std::string getVectorDataLabel(int i) const { return vectorDataLabels_[i]; }
+  [[nodiscard]] int getVectorDataIndex(const std::string &label) const {
+    for (int i = 0; i < (int)vectorDataLabels_.size(); ++i)
+      if (vectorDataLabels_[i] == label)
+        return i;
+    std::cerr << "Can not find vector data label in TracingData.\n";
+    return -1;
+  }
+  [[nodiscard]] TracingDataMergeEnum getVectorMergeType(int num) const { return vectorDataMerge_[num]; }
+};
+
+// ---- particles --------------------------------------------------------------------
+template <typename NumericType> class AbstractParticle {
+public:
+  virtual ~AbstractParticle() = default;
+  virtual std::unique_ptr<AbstractParticle> clone() const = 0;
+  virtual NumericType getSourceDistributionPower() const = 0;
+  [[nodiscard]] virtual std::vector<std::string> getLocalDataLabels() const = 0;
+  // what the device needs to know (built-in particles only)
+  virtual void describe(vr_particle &pod) const = 0;
+};
+
+template <typename NumericType, int D> class DiffuseParticle : public AbstractParticle<NumericType> {
+  NumericType stickingProbability_;
+  std::string dataLabel_;
+
+public:
+  DiffuseParticle(NumericType stickingProbability, std::string dataLabel)
+      : stickingProbability_(stickingProbability), dataLabel_(std::move(dataLabel)) {}
+  std::unique_ptr<AbstractParticle<NumericType>> clone() const final {
+    return std::make_unique<DiffuseParticle>(*this);
+  }
+  NumericType getSourceDistributionPower() const final { return 1.; }
+  [[nodiscard]] std::vector<std::string> getLocalDataLabels() const final { return {dataLabel_}; }
+  void describe(vr_particle &pod) const final {
+    pod = vr_particle{VR_PARTICLE_DIFFUSE, (float)stickingProbability_, 1.f, 0, nullptr, nullptr};
+  }
+};
+
+template <typename NumericType, int D> class SpecularParticle : public AbstractParticle<NumericType> {
+  NumericType stickingProbability_;
+  NumericType sourcePower_;
+  std::string dataLabel_;
+
+public:
+  SpecularParticle(NumericType stickingProbability, NumericType sourcePower, std::string dataLabel)
+      : stickingProbability_(stickingProbability), sourcePower_(sourcePower), dataLabel_(std::move(dataLabel)) {}
+  std::unique_ptr<AbstractParticle<NumericType>> clone() const final {
+    return std::make_unique<SpecularParticle>(*this);
+  }
+  NumericType getSourceDistributionPower() const final { return sourcePower_; }
+  [[nodiscard]] std::vector<std::string> getLocalDataLabels() const final { return {dataLabel_}; }
+  void describe(vr_particle &pod) const final {
+    pod = vr_particle{VR_PARTICLE_SPECULAR, (float)stickingProbability_, (float)sourcePower_, 0, nullptr, nullptr};
+  }
+};
+
+// ---- Trace<T,D> ----------------------------------------------------------------------
+template <class NumericType, int D> class Trace {
+public:
+  Trace() {
+    if (vr_create(&ctx_, 0) != VR_OK) {
+      ctx_ = nullptr;
+      RTInfo_.error = true;
+      std::cerr << "viennaray_amd: no usable HIP device (there is no CPU fallback)\n";
+    }
+  }
+  Trace(const Trace &) = delete;
+  Trace &operator=(const Trace &) = delete;
+  Trace(Trace &&) = delete;
+  Trace &operator=(Trace &&) = delete;
+  virtual ~Trace() { vr_destroy(ctx_); }
+
+  /// Run the ray tracer
+  virtual void apply() {
+    if (!ctx_ || pParticle_ == nullptr) {
+      RTInfo_.error = true;
+      std::cerr << "No particle was specified in rayTrace. Aborting.\n";
+      return;
+    }
+    const int rc = vr_apply(ctx_);
+    vr_trace_info i{};
+    vr_get_trace_info(ctx_, &i);
+    RTInfo_.numRays = i.numRays;
+    RTInfo_.totalRaysTraced = i.totalRaysTraced;
+    RTInfo_.nonGeometryHits = i.nonGeometryHits;
+    RTInfo_.geometryHits = i.geometryHits;
+    RTInfo_.particleHits = i.particleHits;
+    RTInfo_.boundaryHits = i.boundaryHits;
+    RTInfo_.reflections = i.reflections;
+    RTInfo_.time = i.time;
+    RTInfo_.warning = i.warning != 0;
+    RTInfo_.error = i.error != 0 || rc != VR_OK;
+    if (rc != VR_OK) {
+      std::cerr << vr_last_error(ctx_) << "\n";
+      return;
+    }
+    // rayTraceDisk.hpp:40-47: one zero-initialised vector per data label, then the flux
+    auto labels = pParticle_->getLocalDataLabels();
+    localData_.setNumberOfVectorData((int)labels.size());
+    const uint32_t n = vr_num_primitives(ctx_);
+    for (int k = 0; k < (int)labels.size(); ++k)
+      localData_.setVectorData(k, n, NumericType(0), labels[k]);
+    if (!labels.empty()) {
+      if constexpr (std::is_same_v<NumericType, float>) {
+        vr_get_flux(ctx_, localData_.getVectorData(0).data(), n);
+      } else {
+        std::vector<double> tmp(n);
+        vr_get_flux_f64(ctx_, tmp.data(), n);
+        for (uint32_t j = 0; j < n; ++j)
+          localData_.getVectorData(0)[j] = (NumericType)tmp[j];
+      }
+    }
+  }
+
+  template <typename ParticleType,
+            std::enable_if_t<std::is_base_of_v<AbstractParticle<NumericType>, ParticleType>, bool> = true>
+  void setParticleType(std::unique_ptr<ParticleType> const &particle) {
+    pParticle_ = particle->clone();
+    vr_particle pod{};
+    pParticle_->describe(pod);
+    if (ctx_)
+      vr_set_particle(ctx_, &pod);
+  }
+
+  void setBoundaryConditions(BoundaryCondition boundaryConditions[D]) {
+    int32_t b[3] = {0, 0, 0};
+    for (int i = 0; i < D; ++i)
+      b[i] = (int32_t)boundaryConditions[i];
+    if (ctx_)
+      vr_set_boundary_conditions(ctx_, b, D);
+  }
+  void setNumberOfRaysPerPoint(const size_t n) {
+    if (ctx_)
+      vr_set_number_of_rays_per_point(ctx_, n);
+  }
+  void setNumberOfRaysFixed(const size_t n) {
+    if (ctx_)
+      vr_set_number_of_rays_fixed(ctx_, n);
+  }
+  void setMaxReflections(const unsigned n) {
+    if (ctx_)
+      vr_set_max_reflections(ctx_, n);
+  }
+  void setMaxBoundaryHits(const unsigned n) {
+    if (ctx_)
+      vr_set_max_boundary_hits(ctx_, n);
+  }
+  void setSourceDirection(const TraceDirection direction) {
+    if (ctx_)
+      vr_set_source_direction(ctx_, (int)direction);
+  }
+  void setPrimaryDirection(const Vec3D<NumericType> primaryDirection) {
+    const float d[3] = {(float)primaryDirection[0], (float)primaryDirection[1], (float)primaryDirection[2]};
+    if (ctx_)
+      vr_set_primary_direction(ctx_, d);
+  }
+  void setUseRandomSeeds(const bool useRand) {
+    if (ctx_)
+      vr_set_use_random_seeds(ctx_, useRand ? 1 : 0);
+  }
+  void setRngSeed(const unsigned int seed) {
+    if (ctx_)
+      vr_set_rng_seed(ctx_, seed);
+  }
+  void enableProgressBar() {}
+  void disableProgressBar() {}
+
+  virtual void normalizeFlux(std::vector<NumericType> &flux, NormalizationType norm = NormalizationType::SOURCE) {
+    inPlace(flux, [&](float *p, uint32_t n) { return vr_normalize_flux(ctx_, p, n, (int)norm); });
+  }
+  virtual void smoothFlux(std::vector<NumericType> &flux, int numNeighbors = 1) {
+    inPlace(flux, [&](float *p, uint32_t n) { return vr_smooth_flux(ctx_, p, n, numNeighbors); });
+  }
+
+  [[nodiscard]] TracingData<NumericType> &getLocalData() { return localData_; }
+  [[nodiscard]] TraceInfo getRayTraceInfo() const { return RTInfo_; }
+  /// the underlying C-ABI context (multi-GPU drivers use vr_set_ray_range etc.)
+  [[nodiscard]] vr_context *getContext() { return ctx_; }
+
+protected:
+  template <class F> void inPlace(std::vector<NumericType> &flux, F f) {
+    if (!ctx_)
+      return;
+    if constexpr (std::is_same_v<NumericType, float>) {
+      if (f(flux.data(), (uint32_t)flux.size()) != VR_OK)
+        std::cerr << vr_last_error(ctx_) << "\n";
+    } else {
+      std::vector<float> tmp(flux.begin(), flux.end());
+      if (f(tmp.data(), (uint32_t)tmp.size()) != VR_OK)
+        std::cerr << vr_last_error(ctx_) << "\n";
+      std::copy(tmp.begin(), tmp.end(), flux.begin());
+    }
+  }
+  template <class Vec> static std::vector<float> flatten3(const std::vector<Vec> &v) {
+    std::vector<float> out(v.size() * 3, 0.f);
+    for (size_t i = 0; i < v.size(); ++i)
+      for (size_t k = 0; k < v[i].size() && k < 3; ++k)
+        out[3 * i + k] = (float)v[i][k];
+    return out;
+  }
+
+  vr_context *ctx_ = nullptr;
+  std::unique_ptr<AbstractParticle<NumericType>> pParticle_ = nullptr;
+  TracingData<NumericType> localData_;
+  TraceInfo RTInfo_;
+};
+
+template <class NumericType, int D> class TraceDisk final : public Trace<NumericType, D> {
+public:
+  template <size_t Dim>
+  void setGeometry(std::vector<VectorType<NumericType, Dim>> const &points,
+                   std::vector<VectorType<NumericType, Dim>> const &normals, const NumericType gridDelta) {
+    setGeometry(points, normals, gridDelta, NumericType(0));
+  }
+  template <size_t Dim>
+  void setGeometry(std::vector<VectorType<NumericType, Dim>> const &points,
+                   std::vector<VectorType<NumericType, Dim>> const &normals, const NumericType gridDelta,
+                   const NumericType diskRadii) {
+    static_assert(!(D == 3 && Dim == 2), "Setting 2D geometry in 3D trace object");
+    auto p = this->flatten3(points), n = this->flatten3(normals);
+    if (this->ctx_)
+      vr_set_disks(this->ctx_, p.data(), n.data(), (uint32_t)points.size(), (float)gridDelta, (float)diskRadii, D);
+  }
+  void setGeometry(const DiskMesh &mesh) {
+    auto p = this->flatten3(mesh.nodes), n = this->flatten3(mesh.normals);
+    if (this->ctx_)
+      vr_set_disks(this->ctx_, p.data(), n.data(), (uint32_t)mesh.nodes.size(), mesh.gridDelta, 0.f, D);
+  }
+  template <typename T> void setMaterialIds(std::vector<T> const &materialIds) {
+    std::vector<int32_t> ids(materialIds.begin(), materialIds.end());
+    if (this->ctx_)
+      vr_set_material_ids(this->ctx_, ids.data(), (uint32_t)ids.size());
+  }
+};
+
+template <class NumericType, int D> class TraceTriangle final : public Trace<NumericType, D> {
+public:
+  void setGeometry(std::vector<VectorType<NumericType, 3>> const &points,
+                   std::vector<VectorType<unsigned, 3>> const &triangles, const NumericType gridDelta) {
+    auto p = this->flatten3(points);
+    std::vector<uint32_t> t(triangles.size() * 3);
+    for (size_t i = 0; i < triangles.size(); ++i)
+      for (int k = 0; k < 3; ++k)
+        t[3 * i + k] = triangles[i][k];
+    if (this->ctx_)
+      vr_set_triangles(this->ctx_, p.data(), (uint32_t)points.size(), t.data(), (uint32_t)triangles.size(),
+                       (float)gridDelta, D);
+  }
+  void setGeometry(const TriangleMesh &mesh) {
+    std::vector<VectorType<NumericType, 3>> pts(mesh.nodes.size());
+    for (size_t i = 0; i < pts.size(); ++i)
+      pts[i] = {(NumericType)mesh.nodes[i][0], (NumericType)mesh.nodes[i][1], (NumericType)mesh.nodes[i][2]};
+    setGeometry(pts, mesh.triangles, (NumericType)mesh.gridDelta);
+  }
+  template <typename T> void setMaterialIds(std::vector<T> const &materialIds) {
+    std::vector<int32_t> ids(materialIds.begin(), materialIds.end());
+    if (this->ctx_)
+      vr_set_material_ids(this->ctx_, ids.data(), (uint32_t)ids.size());
+  }
+};
+
+} // namespace viennaray
+
+namespace rayInternal {
+using namespace viennaray;
+
+// file formats: rayUtil.hpp:353-411
+template <typename NumericType>
+void readGridFromFile(const std::string &fileName, NumericType &gridDelta, std::vector<Vec3D<NumericType>> &points,
+                      std::vector<Vec3D<NumericType>> &normals) {
+  std::ifstream f(fileName);
+  if (!f.is_open()) {
+    std::cout << "Cannot read file " << fileName << std::endl;
+    return;
+  }
+  size_t n;
+  f >> n >> gridDelta;
+  points.resize(n);
+  normals.resize(n);
+  for (auto &p : points)
+    f >> p[0] >> p[1] >> p[2];
+  for (auto &p : normals)
+    f >> p[0] >> p[1] >> p[2];
+}
+
+template <typename NumericType, int D>
+void readMeshFromFile(const std::string &fileName, NumericType &gridDelta, std::vector<Vec3D<NumericType>> &nodes,
+                      std::vector<VectorType<unsigned, D>> &elements) {
+  std::ifstream f(fileName);
+  if (!f.is_open()) {
+    std::cerr << "Failed to open mesh file: " << fileName << "\n";
+    return;
+  }
+  std::string id;
+  size_t nn = 0, ne = 0;
+  f >> id >> gridDelta >> id >> nn >> id >> ne;
+  nodes.resize(nn);
+  for (auto &p : nodes)
+    f >> id >> p[0] >> p[1] >> p[2];
+  elements.clear();
+  elements.reserve(ne);
+  VectorType<unsigned, D> e;
+  while (elements.size() < ne && (f >> id)) {
+    for (int j = 0; j < D; ++j)
+      f >> e[j];
+    if (f)
+      elements.push_back(e);
+  }
+}
+
+template <typename NumericType>
+void createPlaneGrid(const NumericType gridDelta, const NumericType extent, const std::array<int, 3> direction,
+                     std::vector<Vec3D<NumericType>> &points, std::vector<Vec3D<NumericType>> &normals) {
+  Vec3D<NumericType> point{-extent, -extent, -extent}, normal{0, 0, 0};
+  point[direction[2]] = 0;
+  normal[direction[2]] = 1;
+  points.clear();
+  normals.clear();
+  for (; point[direction[0]] <= extent; point[direction[0]] += gridDelta) {
+    for (point[direction[1]] = -extent; point[direction[1]] <= extent; point[direction[1]] += gridDelta) {
+      points.push_back(point);
+      normals.push_back(normal);
+    }
+  }
+}
+
+template <typename NumericType, int D = 3, typename FluxType = NumericType>
+void writeVTK(const std::string &filename, const std::vector<Vec3D<NumericType>> &points,
+              const std::vector<FluxType> &flux) {
+  std::ofstream f(filename.c_str());
+  f << "# vtk DataFile Version 2.0\n" << D << "D Surface\nASCII\nDATASET UNSTRUCTURED_GRID\n";
+  f << "POINTS " << points.size() << " float\n";
+  for (auto const &p : points)
+    f << p[0] << " " << p[1] << " " << p[2] << "\n";
+  f << "CELLS " << points.size() << " " << points.size() * 2 << "\n";
+  for (size_t i = 0; i < points.size(); ++i)
+    f << "1 " << i << "\n";
+  f << "CELL_TYPES " << points.size() << "\n";
+  for (size_t i = 0; i < points.size(); ++i)
+    f << "1\n";
+  f << "CELL_DATA " << flux.size() << "\nSCALARS flux float\nLOOKUP_TABLE default\n";
+  for (auto v : flux)
+    f << v << "\n";
+}
+} // namespace rayInternal
