@@ -377,3 +377,56 @@ def test_ported_reference_example_runs():
     assert "rays 1445950" in out.stdout
     mean = float(out.stdout.split("mean normalised flux")[1].split()[0])
     assert 0.05 < mean < 1.5
+
+
+@pytest.mark.parametrize("geom", ["plane", "sphere", "trench3d", "trench2d"])
+def test_device_neighbourhood_matches_oracle(geom):
+    """The device-built neighbourhood CSR (BVH range query) holds exactly the
+    reference's pairs (rayPointNeighborhood.hpp:287-298); plane: 8 / 5 / 3
+    (tests/pointNeighborhood/pointNeighborhood.cpp:51)."""
+    D = 3
+    radius = 0.0
+    if geom == "plane":
+        gd = 0.5
+        p, n = vr.io.create_plane_grid(0.5, 10)
+        radius = float(np.float32(0.5) - np.float32(1e-6))
+    else:
+        gd, p, n = {"sphere": sphere3d, "trench3d": trench3d, "trench2d": trench2d}[geom]()
+        D = 2 if geom == "trench2d" else 3
+    t = vr.TraceDisk(D)
+    t.setGeometry(p, n, gd, radius)
+    t.setParticleType(vr.DiffuseParticle(1.0, "f"))
+    t.setNumberOfRaysFixed(256)
+    t.setRngSeed(1)
+    if D == 2:
+        t.setSourceDirection(TD.POS_Y)
+    t.apply()  # builds BVH + neighbourhood on the device
+    got = t.getNeighborCounts()
+    o = po.Oracle()
+    o.set_disks(p, n, gd, D, radius=radius)
+    exp = o.neighbor_counts()
+    assert (got == exp).all()
+    if geom == "plane":
+        assert sorted(set(got.tolist())) == [3, 5, 8]
+
+
+def test_host_and_device_builders_agree(monkeypatch):
+    """VR_HOST_BUILD=1 selects the host LBVH/CSR builder; the flux must not depend
+    on which tree is traversed (closest-hit rule is order independent)."""
+    gd, p, n = trench3d()
+
+    def run():
+        t = vr.TraceDisk(3)
+        t.setGeometry(p, n, gd)
+        t.setBoundaryConditions([BC.REFLECTIVE_BOUNDARY] * 3)
+        t.setParticleType(vr.DiffuseParticle(0.3, "flux"))
+        t.setNumberOfRaysPerPoint(10)
+        t.setRngSeed(11)
+        t.apply()
+        return t.getFluxF64(), info_dict(t), t.debugBvhStats()
+
+    fd, idv, sd = run()
+    monkeypatch.setenv("VR_HOST_BUILD", "1")
+    fh, ih, sh = run()
+    assert (fd == fh).all() and idv == ih
+    assert sh["maxDepth"] > 0 and sd["nodes"] == 2 * len(p) - 1

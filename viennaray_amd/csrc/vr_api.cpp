@@ -93,6 +93,13 @@ struct vr_context {
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
   DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
   size_t scratchWaves = 0;
+  // device-side setup (vr_setup.hip)
+  DevBuf<float> dDisk4, dNormal3, dPoints3, dVerts, dBox, dSBox, dNodeBox;
+  DevBuf<uint32_t> dTris, dBounds, dValsA, dValsB, dSortTable, dRangeLo, dRangeHi, dChildL, dChildR, dParentInt,
+      dParentLeaf, dArrive, dOrder;
+  DevBuf<unsigned long long> dKeysA, dKeysB;
+  bool hostOrderValid = false;   // c->bvh.order mirrors dOrder
+  bool hostNeighborsValid = false;
   // ray stream (one batch)
   DevBuf<float> dGenA, dGenB, dRayA, dRayB, dWalls;
   DevBuf<unsigned long long> dGenTape, dRayTape;
@@ -202,6 +209,7 @@ int vr_set_disks(vr_context *c, const float *points, const float *normals, uint3
   if (!c || !points || !normals || (D != 2 && D != 3) || n >= (1u << 27))
     return fail(c, VR_E_INVALID, "vr_set_disks: bad argument");
   host_set_disks(c->geo, points, normals, n, gridDelta, diskRadius, D);
+  c->hostNeighborsValid = false;
   c->boundFlux = nullptr;
   c->geometryDirty = true;
   c->configDirty = true;
@@ -338,6 +346,195 @@ int vr_set_ray_range(vr_context *c, uint64_t first, uint64_t count) {
   return VR_OK;
 }
 
+// ---- scene build (device LBVH + neighbourhood; VR_HOST_BUILD=1 selects the host builder) -------
+static int ensure_host_order(vr_context *c) {
+  if (c->hostOrderValid)
+    return VR_OK;
+  const uint32_t N = c->geo.numPrims;
+  c->bvh.order.resize(N);
+  VR_HIP(c, hipMemcpy(c->bvh.order.data(), c->dOrder.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+  c->hostOrderValid = true;
+  return VR_OK;
+}
+
+// neighbourhood CSR in ORIGINAL ids on the host (smoothFlux, neighbour counts), lazily
+static int ensure_host_neighbors(vr_context *c) {
+  if (c->hostNeighborsValid)
+    return VR_OK;
+  HostGeometry &g = c->geo;
+  const uint32_t N = g.numPrims;
+  if (g.geo != 0) {
+    g.nbOff.assign((size_t)N + 1, 0u);
+    g.nbIds.clear();
+  } else if (!c->geometryDirty && c->dNbOff.p) {
+    int r = ensure_host_order(c);
+    if (r != VR_OK)
+      return r;
+    std::vector<uint32_t> off((size_t)N + 1);
+    VR_HIP(c, hipMemcpy(off.data(), c->dNbOff.p, ((size_t)N + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> ids(off[N]);
+    if (off[N])
+      VR_HIP(c, hipMemcpy(ids.data(), c->dNbIds.p, (size_t)off[N] * 4, hipMemcpyDeviceToHost));
+    g.nbOff.assign((size_t)N + 1, 0u);
+    for (uint32_t q = 0; q < N; ++q)
+      g.nbOff[c->bvh.order[q] + 1] = off[q + 1] - off[q];
+    for (uint32_t i = 0; i < N; ++i)
+      g.nbOff[i + 1] += g.nbOff[i];
+    g.nbIds.resize(off[N]);
+    for (uint32_t q = 0; q < N; ++q) {
+      uint32_t w = g.nbOff[c->bvh.order[q]];
+      for (uint32_t j = off[q]; j < off[q + 1]; ++j)
+        g.nbIds[w++] = c->bvh.order[ids[j]];
+      std::sort(g.nbIds.begin() + g.nbOff[c->bvh.order[q]], g.nbIds.begin() + w);
+    }
+  } else {
+    host_neighbors(g.D, g.points3.data(), N, 2 * g.diskRadius, g.minC, g.nbOff, g.nbIds);
+  }
+  c->hostNeighborsValid = true;
+  return VR_OK;
+}
+
+static int build_scene(vr_context *c) {
+  HostGeometry &g = c->geo;
+  const uint32_t N = g.numPrims;
+  const bool disk = g.geo == 0;
+  c->hostOrderValid = false;
+  c->hostNeighborsValid = false;
+  VR_HIP(c, c->dLeafOfOrig.ensure(N));
+  VR_HIP(c, c->dOrder.ensure(N));
+  VR_HIP(c, c->dFluxAcc.ensure(N));
+  VR_HIP(c, c->dFluxOrig.ensure(N));
+  VR_HIP(c, c->dCounters.ensure(16));
+  VR_HIP(c, c->dNbOff.ensure((size_t)N + 1));
+  const char *hb = std::getenv("VR_HOST_BUILD");
+  if (hb && std::atoi(hb)) {
+    // host builder (validation path): LBVH + CSR on the CPU, uploaded
+    if (disk)
+      host_neighbors(g.D, g.points3.data(), N, 2 * g.diskRadius, g.minC, g.nbOff, g.nbIds);
+    else
+      g.nbOff.assign((size_t)N + 1, 0u), g.nbIds.clear();
+    c->hostNeighborsValid = true;
+    host_build_bvh(g, c->bvh);
+    c->hostOrderValid = true;
+    std::vector<float> prims;
+    host_pack_prims(g, c->bvh, prims);
+    c->leafOfOrig.resize(N);
+    for (uint32_t q = 0; q < N; ++q)
+      c->leafOfOrig[c->bvh.order[q]] = q;
+    std::vector<uint32_t> off((size_t)N + 1, 0u), ids(g.nbIds.size());
+    for (uint32_t q = 0; q < N; ++q) {
+      const uint32_t o = c->bvh.order[q];
+      off[q + 1] = off[q] + (g.nbOff[o + 1] - g.nbOff[o]);
+    }
+    for (uint32_t q = 0; q < N; ++q) {
+      const uint32_t o = c->bvh.order[q];
+      uint32_t w = off[q];
+      for (uint32_t j = g.nbOff[o]; j < g.nbOff[o + 1]; ++j)
+        ids[w++] = c->leafOfOrig[g.nbIds[j]];
+    }
+    VR_HIP(c, c->dNodes.ensure(c->bvh.nodes.size()));
+    VR_HIP(c, c->dPrims.ensure(prims.size()));
+    VR_HIP(c, c->dNbIds.ensure(ids.size()));
+    VR_HIP(c, hipMemcpyAsync(c->dNodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dPrims.p, prims.data(), prims.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dNbOff.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
+    if (!ids.empty())
+      VR_HIP(c, hipMemcpyAsync(c->dNbIds.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dLeafOfOrig.p, c->leafOfOrig.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dOrder.p, c->bvh.order.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    return VR_OK;
+  }
+
+  // ---- device builder ----
+  SetupParams s{};
+  s.n = N;
+  s.geo = g.geo;
+  s.D = g.D;
+  s.nbDist = 2 * g.diskRadius;
+  VR_HIP(c, c->dNormal3.ensure((size_t)N * 3));
+  VR_HIP(c, hipMemcpyAsync(c->dNormal3.p, g.normal3.data(), (size_t)N * 12, hipMemcpyHostToDevice, c->stream));
+  if (disk) {
+    VR_HIP(c, c->dDisk4.ensure((size_t)N * 4));
+    VR_HIP(c, c->dPoints3.ensure((size_t)N * 3));
+    VR_HIP(c, hipMemcpyAsync(c->dDisk4.p, g.disk4.data(), (size_t)N * 16, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dPoints3.p, g.points3.data(), (size_t)N * 12, hipMemcpyHostToDevice, c->stream));
+  } else {
+    VR_HIP(c, c->dVerts.ensure(g.verts.size()));
+    VR_HIP(c, c->dTris.ensure(g.tris.size()));
+    VR_HIP(c, hipMemcpyAsync(c->dVerts.p, g.verts.data(), g.verts.size() * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dTris.p, g.tris.data(), g.tris.size() * 4, hipMemcpyHostToDevice, c->stream));
+  }
+  const size_t tiles = ((size_t)N + 1023) / 1024;
+  VR_HIP(c, c->dBox.ensure((size_t)N * 6));
+  VR_HIP(c, c->dSBox.ensure((size_t)N * 6));
+  VR_HIP(c, c->dNodeBox.ensure((size_t)N * 6));
+  VR_HIP(c, c->dBounds.ensure(8));
+  VR_HIP(c, c->dKeysA.ensure(N));
+  VR_HIP(c, c->dKeysB.ensure(N));
+  VR_HIP(c, c->dValsA.ensure(N));
+  VR_HIP(c, c->dValsB.ensure(N));
+  VR_HIP(c, c->dSortTable.ensure(256 * tiles));
+  VR_HIP(c, c->dRangeLo.ensure(N));
+  VR_HIP(c, c->dRangeHi.ensure(N));
+  VR_HIP(c, c->dChildL.ensure(N));
+  VR_HIP(c, c->dChildR.ensure(N));
+  VR_HIP(c, c->dParentInt.ensure(N));
+  VR_HIP(c, c->dParentLeaf.ensure(N));
+  VR_HIP(c, c->dArrive.ensure(N));
+  VR_HIP(c, c->dNodes.ensure(((size_t)2 * N) * 8));
+  VR_HIP(c, c->dPrims.ensure((size_t)N * (disk ? 8 : 16)));
+  VR_HIP(c, c->dScanTmp.ensure(2 * ((256 * tiles + (size_t)N + 1) / 2048 + 4) + 64));
+  s.disk4 = c->dDisk4.p;
+  s.normal3 = c->dNormal3.p;
+  s.points3 = c->dPoints3.p;
+  s.verts = c->dVerts.p;
+  s.tris = c->dTris.p;
+  s.box = c->dBox.p;
+  s.sbox = c->dSBox.p;
+  s.bounds = c->dBounds.p;
+  s.keysA = c->dKeysA.p;
+  s.keysB = c->dKeysB.p;
+  s.valsA = c->dValsA.p;
+  s.valsB = c->dValsB.p;
+  s.sortTable = c->dSortTable.p;
+  s.rangeLo = c->dRangeLo.p;
+  s.rangeHi = c->dRangeHi.p;
+  s.childL = c->dChildL.p;
+  s.childR = c->dChildR.p;
+  s.parentInt = c->dParentInt.p;
+  s.parentLeaf = c->dParentLeaf.p;
+  s.arrive = c->dArrive.p;
+  s.nodeBox = c->dNodeBox.p;
+  s.nodes = c->dNodes.p;
+  s.prims = c->dPrims.p;
+  s.leafOfOrig = c->dLeafOfOrig.p;
+  s.order = c->dOrder.p;
+  s.nbOff = c->dNbOff.p;
+  s.nbIds = nullptr;
+  VR_HIP(c, launch_setup_bvh(s, c->dScanTmp.p, c->stream));
+  if (disk) {
+    // neighbourhood: count -> scan -> fill
+    VR_HIP(c, hipMemsetAsync(c->dNbOff.p + N, 0, 4, c->stream));
+    VR_HIP(c, launch_setup_neighbors(s, 0, c->stream));
+    VR_HIP(c, launch_scan(c->dNbOff.p, N + 1, c->dScanTmp.p, c->stream));
+    uint32_t total = 0;
+    VR_HIP(c, hipMemcpyAsync(&total, c->dNbOff.p + N, 4, hipMemcpyDeviceToHost, c->stream));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    VR_HIP(c, c->dNbIds.ensure(total));
+    s.nbIds = c->dNbIds.p;
+    VR_HIP(c, launch_setup_neighbors(s, 1, c->stream));
+  } else {
+    VR_HIP(c, hipMemsetAsync(c->dNbOff.p, 0, ((size_t)N + 1) * 4, c->stream));
+    VR_HIP(c, c->dNbIds.ensure(1));
+  }
+  VR_HIP(c, hipStreamSynchronize(c->stream));
+  c->bvh.numNodes = 2 * N - 1;
+  c->bvh.numLeaves = 0;
+  c->bvh.maxDepth = 0;
+  return VR_OK;
+}
+
 // ---- run ----------------------------------------------------------------------
 static int effective_direction(const vr_context *c) {
   if (c->sourceDirection >= 0)
@@ -405,45 +602,18 @@ int vr_apply_prepare(vr_context *c) {
 
   const uint32_t N = c->geo.numPrims;
   if (c->geometryDirty) {
-    host_build_bvh(c->geo, c->bvh);
-    std::vector<float> prims;
-    host_pack_prims(c->geo, c->bvh, prims);
-    c->leafOfOrig.resize(N);
-    for (uint32_t q = 0; q < N; ++q)
-      c->leafOfOrig[c->bvh.order[q]] = q;
-    // neighbourhood CSR in leaf order
-    std::vector<uint32_t> off((size_t)N + 1, 0u), ids(c->geo.nbIds.size());
-    for (uint32_t q = 0; q < N; ++q) {
-      const uint32_t o = c->bvh.order[q];
-      off[q + 1] = off[q] + (c->geo.nbOff[o + 1] - c->geo.nbOff[o]);
-    }
-    for (uint32_t q = 0; q < N; ++q) {
-      const uint32_t o = c->bvh.order[q];
-      uint32_t w = off[q];
-      for (uint32_t j = c->geo.nbOff[o]; j < c->geo.nbOff[o + 1]; ++j)
-        ids[w++] = c->leafOfOrig[c->geo.nbIds[j]];
-    }
-    VR_HIP(c, c->dNodes.ensure(c->bvh.nodes.size()));
-    VR_HIP(c, c->dPrims.ensure(prims.size()));
-    VR_HIP(c, c->dNbOff.ensure(off.size()));
-    VR_HIP(c, c->dNbIds.ensure(ids.size()));
-    VR_HIP(c, c->dLeafOfOrig.ensure(N));
-    VR_HIP(c, c->dFluxAcc.ensure(N));
-    VR_HIP(c, c->dFluxOrig.ensure(N));
-    VR_HIP(c, c->dCounters.ensure(16));
-    VR_HIP(c, hipMemcpyAsync(c->dNodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * 4, hipMemcpyHostToDevice, c->stream));
-    VR_HIP(c, hipMemcpyAsync(c->dPrims.p, prims.data(), prims.size() * 4, hipMemcpyHostToDevice, c->stream));
-    VR_HIP(c, hipMemcpyAsync(c->dNbOff.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
-    if (!ids.empty())
-      VR_HIP(c, hipMemcpyAsync(c->dNbIds.p, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, c->stream));
-    VR_HIP(c, hipMemcpyAsync(c->dLeafOfOrig.p, c->leafOfOrig.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
-    VR_HIP(c, hipStreamSynchronize(c->stream));
+    int r = build_scene(c);
+    if (r != VR_OK)
+      return r;
     c->geometryDirty = false;
   }
   // per-primitive sticking from the material map (gpu::Particle-style, rayParticle.hpp:208-218)
   if (redoConfig)
     c->havePrimSticking = false;
   if (redoConfig && !c->matStickIds.empty()) {
+    int ro = ensure_host_order(c);
+    if (ro != VR_OK)
+      return ro;
     std::vector<float> ps(N);
     for (uint32_t q = 0; q < N; ++q) {
       const uint32_t o = c->bvh.order[q];
@@ -812,6 +982,11 @@ int vr_smooth_flux(vr_context *c, float *flux, uint32_t n, int numNeighbors) {
     return fail(c, VR_E_INVALID, "vr_smooth_flux: bad argument");
   if (c->geo.geo != 0 || numNeighbors < 1)
     return VR_OK;
+  if (numNeighbors == 1) {
+    int r = ensure_host_neighbors(c);
+    if (r != VR_OK)
+      return r;
+  }
   const std::vector<uint32_t> *off = &c->geo.nbOff, *ids = &c->geo.nbIds;
   std::vector<uint32_t> woff, wids;
   if (numNeighbors != 1) {
@@ -861,6 +1036,9 @@ float vr_get_disk_radius(const vr_context *c) { return c ? c->geo.diskRadius : 0
 int vr_get_neighbor_counts(vr_context *c, uint32_t *out, uint32_t n) {
   if (!c || !out || n != c->geo.numPrims)
     return VR_E_INVALID;
+  int r = ensure_host_neighbors(c);
+  if (r != VR_OK)
+    return r;
   for (uint32_t i = 0; i < n; ++i)
     out[i] = c->geo.nbOff[i + 1] - c->geo.nbOff[i];
   return VR_OK;

@@ -73,8 +73,10 @@ void host_set_disks(HostGeometry &g, const float *pts, const float *nrm, uint32_
   }
   if (g.materialIds.size() != n)
     g.materialIds.assign(n, 0);
-  // rayGeometryDisk.hpp:191-192: neighbourhood radius = 2 * disk radius
-  host_neighbors(D, g.points3.data(), n, 2 * g.diskRadius, g.minC, g.nbOff, g.nbIds);
+  // the neighbourhood (rayGeometryDisk.hpp:191-192, radius = 2 * disk radius) is built
+  // on the device with the BVH (vr_setup.hip); the host version is a validation path
+  g.nbOff.clear();
+  g.nbIds.clear();
   g.verts.clear();
   g.tris.clear();
   g.triAreas.clear();

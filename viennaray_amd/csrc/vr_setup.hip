@@ -1,0 +1,466 @@
+// vr_setup.hip — device-side scene setup: LBVH build and disk-neighbourhood CSR.
+//
+// The reference builds its acceleration structure inside the timed region
+// (rtcJoinCommitScene, rayTraceKernel.hpp:91) and its point
+// neighbourhood at setGeometry (rayGeometryDisk.hpp:191-192, recursive host
+// vectors).  Here both are HIP kernels:
+//
+//   prim_box_kernel     primitive AABBs (oriented-disc extents r*sqrt(1-n_k^2),
+//                       triangle min/max) + scene bounds (ordered-int atomics)
+//   morton_kernel       63-bit Morton code of each box centre
+//   radix sort          LSD, 8-bit digits, one wavefront per 1024-key tile,
+//                       ballot-based stable ranking (no LDS scatter buffers)
+//   karras_kernel       binary radix tree over the sorted codes (Karras 2012)
+//   fit_kernel          bottom-up AABB fit with arrival counters
+//   finalize_kernel     traversal nodes {lo,link}{hi,escape}: ranges of <= 4
+//                       primitives collapse into leaves, escape links by parent walk
+//   pack_*_kernel       primitive records in leaf order
+//   nb_count / nb_fill  neighbourhood = stackless BVH range query around every
+//                       disc centre (per-axis |d| <= dist and |d|^2 <= dist^2,
+//                       rayPointNeighborhood.hpp:287-298), written as CSR of leaf
+//                       positions
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "vr_kernels.hpp"
+#include "vr_types.hpp"
+
+namespace vr {
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------------------
+// float <-> order-preserving uint (for atomicMin/Max on floats)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned f2ord(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(unsigned u) {
+  unsigned v = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+#ifdef __HIP_DEVICE_COMPILE__
+  return __uint_as_float(v);
+#else
+  float f;
+  __builtin_memcpy(&f, &v, 4);
+  return f;
+#endif
+}
+
+// bounds[0..2] = min (ordered), bounds[3..5] = max (ordered)
+__global__ void prim_box_kernel(SetupParams s) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (i < s.n) {
+    if (s.geo == 0) {
+      const float4 d = reinterpret_cast<const float4 *>(s.disk4)[i];
+      float nx = s.normal3[3 * (size_t)i], ny = s.normal3[3 * (size_t)i + 1], nz = s.normal3[3 * (size_t)i + 2];
+      const float nn = sqrtf((nx * nx + ny * ny) + nz * nz);
+      if (nn > 0.f) {
+        nx /= nn;
+        ny /= nn;
+        nz /= nn;
+      }
+      const float c[3] = {d.x, d.y, d.z}, nv[3] = {nx, ny, nz};
+      for (int k = 0; k < 3; ++k) {
+        const float h = d.w * sqrtf(fmaxf(0.f, 1.f - nv[k] * nv[k])) * 1.0001f;
+        lo[k] = c[k] - h;
+        hi[k] = c[k] + h;
+      }
+    } else {
+      const unsigned a = s.tris[3 * (size_t)i], b = s.tris[3 * (size_t)i + 1], c = s.tris[3 * (size_t)i + 2];
+      for (int k = 0; k < 3; ++k) {
+        const float v0 = s.verts[3 * (size_t)a + k], v1 = s.verts[3 * (size_t)b + k], v2 = s.verts[3 * (size_t)c + k];
+        lo[k] = fminf(v0, fminf(v1, v2));
+        hi[k] = fmaxf(v0, fmaxf(v1, v2));
+      }
+    }
+    float *b = s.box + 6 * (size_t)i;
+    for (int k = 0; k < 3; ++k) {
+      b[k] = lo[k];
+      b[3 + k] = hi[k];
+    }
+  }
+  // wave reduce then one atomic per wave
+  for (int k = 0; k < 3; ++k) {
+    float a = lo[k], b = hi[k];
+    for (int off = 32; off > 0; off >>= 1) {
+      a = fminf(a, __shfl_down(a, off, 64));
+      b = fmaxf(b, __shfl_down(b, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&s.bounds[k], f2ord(a));
+      atomicMax(&s.bounds[3 + k], f2ord(b));
+    }
+  }
+}
+
+__device__ __forceinline__ u64 spread21(u64 v) {
+  v &= 0x1FFFFFull;
+  v = (v | v << 32) & 0x1F00000000FFFFull;
+  v = (v | v << 16) & 0x1F0000FF0000FFull;
+  v = (v | v << 8) & 0x100F00F00F00F00Full;
+  v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+  v = (v | v << 2) & 0x1249249249249249ull;
+  return v;
+}
+
+// pads the boxes (more than the rounding of the slab test) and computes codes
+__global__ void morton_kernel(SetupParams s) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n)
+    return;
+  float slo[3], shi[3], scale = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    slo[k] = ord2f(s.bounds[k]);
+    shi[k] = ord2f(s.bounds[3 + k]);
+    scale = fmaxf(scale, fmaxf(fabsf(slo[k]), fabsf(shi[k])));
+  }
+  const float pad = 4e-6f * fmaxf(scale, 1e-3f);
+  float *b = s.box + 6 * (size_t)i;
+  u64 q[3];
+  for (int k = 0; k < 3; ++k) {
+    const float ext = shi[k] - slo[k];
+    const float inv = ext > 0.f ? 2097151.0f / ext : 0.f;
+    float c = (0.5f * (b[k] + b[3 + k]) - slo[k]) * inv;
+    c = fminf(fmaxf(c, 0.f), 2097151.0f);
+    q[k] = (u64)c;
+    b[k] -= pad;
+    b[3 + k] += pad;
+  }
+  s.keysA[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  s.valsA[i] = i;
+}
+
+// ---------------------------------------------------------------------------
+// LSD radix sort, one wavefront per tile of 1024 keys
+// ---------------------------------------------------------------------------
+constexpr unsigned SORT_TILE = 1024;
+
+__global__ __launch_bounds__(64) void sort_count_kernel(const u64 *keys, unsigned n, unsigned shift, unsigned tiles,
+                                                        unsigned *table) {
+  __shared__ unsigned hist[256];
+  const unsigned lane = threadIdx.x, tile = blockIdx.x;
+  for (unsigned k = lane; k < 256; k += 64)
+    hist[k] = 0;
+  __syncthreads();
+  for (unsigned it = 0; it < SORT_TILE / 64; ++it) {
+    const unsigned idx = tile * SORT_TILE + it * 64 + lane;
+    if (idx < n)
+      atomicAdd(&hist[(unsigned)(keys[idx] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  for (unsigned k = lane; k < 256; k += 64)
+    table[k * tiles + tile] = hist[k];
+}
+
+__global__ __launch_bounds__(64) void sort_scatter_kernel(const u64 *keysIn, const unsigned *valsIn, u64 *keysOut,
+                                                          unsigned *valsOut, unsigned n, unsigned shift,
+                                                          unsigned tiles, const unsigned *table) {
+  __shared__ unsigned offs[256];
+  const unsigned lane = threadIdx.x, tile = blockIdx.x;
+  for (unsigned k = lane; k < 256; k += 64)
+    offs[k] = table[k * tiles + tile];
+  __syncthreads();
+  const u64 ltMask = (1ull << lane) - 1ull;
+  for (unsigned it = 0; it < SORT_TILE / 64; ++it) {
+    const unsigned idx = tile * SORT_TILE + it * 64 + lane;
+    const bool valid = idx < n;
+    u64 key = 0;
+    unsigned val = 0, d = 0;
+    if (valid) {
+      key = keysIn[idx];
+      val = valsIn[idx];
+      d = (unsigned)(key >> shift) & 255u;
+    }
+    // lanes holding the same digit: AND of 8 per-bit ballots
+    u64 peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const u64 m = __ballot(valid && ((d >> b) & 1u));
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    if (valid) {
+      const unsigned rank = __popcll(peers & ltMask);
+      const unsigned base = offs[d];
+      keysOut[base + rank] = key;
+      valsOut[base + rank] = val;
+      if (rank == 0)
+        offs[d] = base + __popcll(peers); // in-order LDS: every peer has read `base`
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Karras binary radix tree
+// ---------------------------------------------------------------------------
+constexpr unsigned CHILD_LEAF = 0x80000000u; // child is the singleton leaf of that sorted position
+
+__device__ __forceinline__ int delta(const u64 *code, int n, int i, int j) {
+  if (j < 0 || j >= n)
+    return -1;
+  const u64 a = code[i], b = code[j];
+  if (a == b)
+    return 64 + __clz((unsigned)i ^ (unsigned)j);
+  return __clzll((long long)(a ^ b));
+}
+
+__global__ void karras_kernel(SetupParams s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = (int)s.n;
+  if (i >= n - 1)
+    return;
+  const u64 *code = s.keysA;
+  const int d = (delta(code, n, i, i + 1) - delta(code, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(code, n, i, i - d);
+  int lmax = 2;
+  while (delta(code, n, i, i + lmax * d) > dmin)
+    lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (delta(code, n, i, i + (l + t) * d) > dmin)
+      l += t;
+  const int j = i + l * d;
+  const int dnode = delta(code, n, i, j);
+  int sp = 0;
+  int t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (delta(code, n, i, i + (sp + t) * d) > dnode)
+      sp += t;
+  } while (t > 1);
+  const int gamma = i + sp * d + (d < 0 ? d : 0);
+  const int lo = i < j ? i : j, hi = i < j ? j : i;
+  const unsigned left = (lo == gamma) ? (CHILD_LEAF | (unsigned)gamma) : (unsigned)gamma;
+  const unsigned right = (hi == gamma + 1) ? (CHILD_LEAF | (unsigned)(gamma + 1)) : (unsigned)(gamma + 1);
+  s.rangeLo[i] = (unsigned)lo;
+  s.rangeHi[i] = (unsigned)hi;
+  s.childL[i] = left;
+  s.childR[i] = right;
+  // parent links; bit 31 of the stored parent marks "I am the right child"
+  if (left & CHILD_LEAF)
+    s.parentLeaf[left & ~CHILD_LEAF] = (unsigned)i;
+  else
+    s.parentInt[left] = (unsigned)i;
+  if (right & CHILD_LEAF)
+    s.parentLeaf[right & ~CHILD_LEAF] = (unsigned)i | 0x80000000u;
+  else
+    s.parentInt[right] = (unsigned)i | 0x80000000u;
+}
+
+// bottom-up AABB fit: thread = sorted position; the second arriver at a node fits it
+__global__ void fit_kernel(SetupParams s) {
+  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= s.n || s.n < 2)
+    return;
+  unsigned p = s.parentLeaf[q] & 0x7FFFFFFFu;
+  for (;;) {
+    __threadfence();
+    if (atomicAdd(&s.arrive[p], 1u) == 0u)
+      return; // first arriver: the sibling will come
+    const unsigned L = s.childL[p], R = s.childR[p];
+    const float *a = (L & CHILD_LEAF) ? s.sbox + 6 * (size_t)(L & ~CHILD_LEAF) : s.nodeBox + 6 * (size_t)L;
+    const float *b = (R & CHILD_LEAF) ? s.sbox + 6 * (size_t)(R & ~CHILD_LEAF) : s.nodeBox + 6 * (size_t)R;
+    float *o = s.nodeBox + 6 * (size_t)p;
+    for (int k = 0; k < 3; ++k) {
+      o[k] = fminf(__hip_atomic_load(&a[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   __hip_atomic_load(&b[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      o[3 + k] = fmaxf(__hip_atomic_load(&a[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(&b[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    if (p == 0)
+      return;
+    p = s.parentInt[p] & 0x7FFFFFFFu;
+  }
+}
+
+// node numbering of the traversal array: internal node i -> i, singleton leaf of
+// sorted position q -> (n - 1) + q
+__device__ __forceinline__ unsigned node_of_child(const SetupParams &s, unsigned c) {
+  return (c & CHILD_LEAF) ? (s.n - 1u) + (c & ~CHILD_LEAF) : c;
+}
+
+// escape of a node = right sibling of the first ancestor-or-self that is a left child
+__device__ __forceinline__ unsigned escape_of(const SetupParams &s, unsigned parentWord) {
+  unsigned pw = parentWord; // parent index | right-child flag of the current node
+  for (;;) {
+    const unsigned p = pw & 0x7FFFFFFFu;
+    if (!(pw & 0x80000000u))
+      return node_of_child(s, s.childR[p]); // current node is the left child
+    if (p == 0)
+      return VR_END;
+    pw = s.parentInt[p];
+  }
+}
+
+__global__ void finalize_kernel(SetupParams s) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned n = s.n;
+  float4 *nodes = reinterpret_cast<float4 *>(s.nodes);
+  if (n == 1) {
+    if (t == 0) {
+      const float *b = s.sbox;
+      nodes[0] = make_float4(b[0], b[1], b[2], __uint_as_float(VR_LEAF | (1u << 27) | 0u));
+      nodes[1] = make_float4(b[3], b[4], b[5], __uint_as_float(VR_END));
+    }
+    return;
+  }
+  if (t < n - 1) { // internal node t
+    const unsigned lo = s.rangeLo[t], hi = s.rangeHi[t], cnt = hi - lo + 1;
+    const float *b = s.nodeBox + 6 * (size_t)t;
+    const unsigned link = cnt <= (unsigned)VR_LEAF_MAX ? (VR_LEAF | (cnt << 27) | lo) : node_of_child(s, s.childL[t]);
+    const unsigned esc = t == 0 ? VR_END : escape_of(s, s.parentInt[t]);
+    nodes[2 * (size_t)t] = make_float4(b[0], b[1], b[2], __uint_as_float(link));
+    nodes[2 * (size_t)t + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(esc));
+  } else if (t < 2 * n - 1) { // singleton leaf of sorted position q
+    const unsigned q = t - (n - 1);
+    const float *b = s.sbox + 6 * (size_t)q;
+    const unsigned esc = escape_of(s, s.parentLeaf[q]);
+    nodes[2 * (size_t)t] = make_float4(b[0], b[1], b[2], __uint_as_float(VR_LEAF | (1u << 27) | q));
+    nodes[2 * (size_t)t + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(esc));
+  }
+}
+
+// sorted boxes, leafOfOrig, primitive records in leaf order
+__global__ void pack_kernel(SetupParams s) {
+  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= s.n)
+    return;
+  const unsigned o = s.valsA[q];
+  s.leafOfOrig[o] = q;
+  s.order[q] = o;
+  for (int k = 0; k < 6; ++k)
+    s.sbox[6 * (size_t)q + k] = s.box[6 * (size_t)o + k];
+  float4 *pr = reinterpret_cast<float4 *>(s.prims);
+  if (s.geo == 0) {
+    pr[2 * (size_t)q] = reinterpret_cast<const float4 *>(s.disk4)[o];
+    pr[2 * (size_t)q + 1] = make_float4(s.normal3[3 * (size_t)o], s.normal3[3 * (size_t)o + 1],
+                                        s.normal3[3 * (size_t)o + 2], __uint_as_float(o));
+  } else {
+    const float *a = s.verts + 3 * (size_t)s.tris[3 * (size_t)o];
+    const float *b = s.verts + 3 * (size_t)s.tris[3 * (size_t)o + 1];
+    const float *c = s.verts + 3 * (size_t)s.tris[3 * (size_t)o + 2];
+    const float e1[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]};
+    const float e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+    // Ng = cross(e2, e1), separate multiplies and subtract (no contraction)
+    const float Ng[3] = {e2[1] * e1[2] - e2[2] * e1[1], e2[2] * e1[0] - e2[0] * e1[2], e2[0] * e1[1] - e2[1] * e1[0]};
+    const float *nn = s.normal3 + 3 * (size_t)o;
+    pr[4 * (size_t)q] = make_float4(a[0], a[1], a[2], __uint_as_float(o));
+    pr[4 * (size_t)q + 1] = make_float4(e1[0], e1[1], e1[2], nn[0]);
+    pr[4 * (size_t)q + 2] = make_float4(e2[0], e2[1], e2[2], nn[1]);
+    pr[4 * (size_t)q + 3] = make_float4(Ng[0], Ng[1], Ng[2], nn[2]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// neighbourhood by BVH range query (disks).  Pass 0 counts, pass 1 fills.
+// The caller's points (not the float4 disc buffer) define the distance test,
+// like the reference (rayGeometryDisk.hpp:191: `init<Dim>(points, ...)`).
+// ---------------------------------------------------------------------------
+template <int PASS> __global__ void nb_kernel(SetupParams s) {
+  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= s.n)
+    return;
+  const float4 *nodes = reinterpret_cast<const float4 *>(s.nodes);
+  const unsigned me = s.order[q];
+  const float px = s.points3[3 * (size_t)me], py = s.points3[3 * (size_t)me + 1], pz = s.points3[3 * (size_t)me + 2];
+  const float dist = s.nbDist, dist2 = dist * dist;
+  // query box: every disc whose centre is within `dist` has that centre inside it,
+  // and a disc's box contains its centre
+  const float qlo[3] = {px - dist, py - dist, s.D == 2 ? -FLT_MAX : pz - dist};
+  const float qhi[3] = {px + dist, py + dist, s.D == 2 ? FLT_MAX : pz + dist};
+  unsigned count = 0;
+  const unsigned base = PASS ? s.nbOff[q] : 0u;
+  unsigned node = 0;
+  while (node != VR_END) {
+    const float4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
+    const unsigned link = __float_as_uint(a.w), esc = __float_as_uint(b.w);
+    const bool hit = a.x <= qhi[0] && b.x >= qlo[0] && a.y <= qhi[1] && b.y >= qlo[1] && a.z <= qhi[2] && b.z >= qlo[2];
+    if (hit) {
+      if (link & VR_LEAF) {
+        const unsigned first = link & VR_LEAF_FIRST_MASK, cnt = (link >> 27) & 15u;
+        for (unsigned k = 0; k < cnt; ++k) {
+          const unsigned r = first + k;
+          if (r == q)
+            continue;
+          const unsigned o = s.order[r];
+          const float dx = px - s.points3[3 * (size_t)o], dy = py - s.points3[3 * (size_t)o + 1],
+                      dz = pz - s.points3[3 * (size_t)o + 2];
+          bool near = fabsf(dx) <= dist && fabsf(dy) <= dist && (s.D == 2 || fabsf(dz) <= dist);
+          near = near && ((dx * dx + dy * dy) + dz * dz) <= dist2;
+          if (near) {
+            if (PASS)
+              s.nbIds[base + count] = r;
+            ++count;
+          }
+        }
+        node = esc;
+      } else {
+        node = link;
+      }
+    } else {
+      node = esc;
+    }
+  }
+  if (!PASS)
+    s.nbOff[q] = count;
+}
+
+// ---------------------------------------------------------------------------
+hipError_t launch_setup_bvh(const SetupParams &sp, unsigned *scanTmp, hipStream_t st) {
+  SetupParams s = sp;
+  const unsigned n = s.n;
+  if (n == 0)
+    return hipSuccess;
+  const unsigned g256 = (n + 255) / 256;
+  // bounds init: min = ord(+inf side), max = ord(-inf side)
+  const unsigned initB[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+  hipError_t e = hipMemcpyAsync(s.bounds, initB, sizeof(initB), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess)
+    return e;
+  hipLaunchKernelGGL(prim_box_kernel, dim3(g256), dim3(256), 0, st, s);
+  hipLaunchKernelGGL(morton_kernel, dim3(g256), dim3(256), 0, st, s);
+  // radix sort (keysA, valsA) -> ping-pong with (keysB, valsB), 8 passes end in A
+  const unsigned tiles = (n + SORT_TILE - 1) / SORT_TILE;
+  u64 *kin = s.keysA, *kout = s.keysB;
+  unsigned *vin = s.valsA, *vout = s.valsB;
+  for (unsigned pass = 0; pass < 8; ++pass) {
+    hipLaunchKernelGGL(sort_count_kernel, dim3(tiles), dim3(64), 0, st, kin, n, pass * 8, tiles, s.sortTable);
+    e = launch_scan(s.sortTable, 256u * tiles, scanTmp, st);
+    if (e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(tiles), dim3(64), 0, st, kin, vin, kout, vout, n, pass * 8, tiles,
+                       s.sortTable);
+    u64 *tk = kin;
+    kin = kout;
+    kout = tk;
+    unsigned *tv = vin;
+    vin = vout;
+    vout = tv;
+  }
+  // (8 passes: result is back in A)
+  hipLaunchKernelGGL(pack_kernel, dim3(g256), dim3(256), 0, st, s);
+  if (n > 1) {
+    e = hipMemsetAsync(s.arrive, 0, (size_t)(n - 1) * 4, st);
+    if (e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL(karras_kernel, dim3((n - 1 + 255) / 256), dim3(256), 0, st, s);
+    hipLaunchKernelGGL(fit_kernel, dim3(g256), dim3(256), 0, st, s);
+  }
+  hipLaunchKernelGGL(finalize_kernel, dim3((2 * n - 1 + 255) / 256), dim3(256), 0, st, s);
+  return hipGetLastError();
+}
+
+hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st) {
+  const unsigned g = (s.n + 255) / 256;
+  if (s.n == 0)
+    return hipSuccess;
+  if (pass == 0)
+    hipLaunchKernelGGL((nb_kernel<0>), dim3(g), dim3(256), 0, st, s);
+  else
+    hipLaunchKernelGGL((nb_kernel<1>), dim3(g), dim3(256), 0, st, s);
+  return hipGetLastError();
+}
+
+} // namespace vr

@@ -81,6 +81,31 @@ struct TraceParams {
   uint32_t debugFlags;            // VR_DEBUG_FLAGS (timing experiments; 0 in production)
 };
 
+// device-side scene setup (vr_setup.hip)
+struct SetupParams {
+  // inputs (device copies of the caller's arrays)
+  const float *disk4;     // n x {x,y,z,r}
+  const float *normal3;   // n x 3 (disk normals / triangle unit normals)
+  const float *points3;   // n x 3 caller's points (neighbourhood)
+  const float *verts;     // nv x 3
+  const uint32_t *tris;   // n x 3
+  uint32_t n;
+  int32_t geo, D;
+  float nbDist;
+  // work buffers
+  float *box, *sbox;      // 6 per primitive: original order / sorted order
+  uint32_t *bounds;       // 6 ordered-uint scene bounds
+  unsigned long long *keysA, *keysB;
+  uint32_t *valsA, *valsB, *sortTable;
+  uint32_t *rangeLo, *rangeHi, *childL, *childR, *parentInt, *parentLeaf, *arrive;
+  float *nodeBox;         // 6 per internal node
+  // outputs
+  float *nodes;           // (2n-1) x 8 floats
+  float *prims;
+  uint32_t *leafOfOrig, *order;
+  uint32_t *nbOff, *nbIds;
+};
+
 // counters[] slots
 enum {
   C_TRACES = 0,
