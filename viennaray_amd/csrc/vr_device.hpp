@@ -116,6 +116,27 @@ __device__ __forceinline__ void rng_init(Rng &r, unsigned seed, u64 *tapeLane, u
   }
 }
 
+// First K outputs of the engine, all in registers (static indexing): what the
+// generator needs when the number of draws is known at compile time.
+template <int K> __device__ __forceinline__ void mt_first_outputs(unsigned seed, u64 (&out)[K]) {
+  u64 w[K + 1];
+  u64 x = seed;
+  w[0] = x;
+#pragma unroll
+  for (int j = 1; j <= K; ++j) {
+    x = mt_step(x, j);
+    w[j] = x;
+  }
+#pragma unroll 4
+  for (int j = K + 1; j < 156; ++j)
+    x = mt_step(x, j);
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    x = mt_step(x, 156 + i);
+    out[i] = mt_temper(mt_twist(w[i], w[i + 1], x));
+  }
+}
+
 __device__ __noinline__ void rng_tier2_build(Rng &r) {
   u64 *s = r.scratch;
   u64 x = r.seed;
@@ -376,17 +397,48 @@ template <int D> __device__ __forceinline__ V3 project_dir(V3 d) {
   return d;
 }
 
+// sin/cos of x in [0, 2*pi] in double: quadrant reduction with a two-part pi/2
+// and the classic degree-13/14 minimax kernels on [-pi/4, pi/4] (error < 1 ulp of
+// double, i.e. ~1e-9 ulp of the float the result is rounded to).
+__device__ __forceinline__ void sincos_0_2pi(double x, double &s, double &c) {
+  const double n = rint(x * 6.36619772367581382433e-01); // 2/pi
+  double r = x - n * 1.57079632673412561417e+00;         // pi/2, high 33 bits
+  r = r - n * 6.07710050650619224932e-11;                // pi/2, tail
+  const double z = r * r;
+  const double ps = -1.66666666666666324348e-01 +
+                    z * (8.33333333332248946124e-03 +
+                         z * (-1.98412698298579493134e-04 +
+                              z * (2.75573137070700676789e-06 +
+                                   z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+  const double pc = 4.16666666666666019037e-02 +
+                    z * (-1.38888888888741095749e-03 +
+                         z * (2.48015872894767294178e-05 +
+                              z * (-2.75573143513906633035e-07 +
+                                   z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+  const double sr = r + r * z * ps;
+  const double cr = 1.0 - 0.5 * z + z * z * pc;
+  const int q = (int)n & 3;
+  const double ss = (q & 1) ? cr : sr;
+  const double cc = (q & 1) ? sr : cr;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // raySourceRandom.hpp:70-116: one power-cosine sample in the local frame.
 // glibc's sincosf/powf are stood in for by double-precision evaluation rounded
 // to float (differs from glibc in ~1 % of samples by 1 ulp).
+template <bool HALF>
 __device__ __forceinline__ void cosine_sample(float r1, float r2, float ee, float &cosTheta, float &sinTheta,
                                               float &cosPhi, float &sinPhi) {
   const float ang = (float)(3.14159265358979323846 * 2. * (double)r1);
   double s, c;
-  sincos((double)ang, &s, &c);
+  sincos_0_2pi((double)ang, s, c);
   sinPhi = (float)s;
   cosPhi = (float)c;
-  cosTheta = (float)pow((double)r2, (double)ee);
+  if (HALF) // cosine source (power 1, ee == 1/2): pow(x, 1/2) correctly rounded = sqrt
+    cosTheta = (float)sqrt((double)r2);
+  else
+    cosTheta = (float)pow((double)r2, (double)ee);
   sinTheta = (float)sqrt(1. - (double)(cosTheta * cosTheta));
 }
 

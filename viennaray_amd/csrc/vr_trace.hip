@@ -33,25 +33,26 @@ __device__ __forceinline__ u64 weight_fx(float w) { return (u64)((double)w * 109
 // ---------------------------------------------------------------------------
 // source sampling (raySourceRandom.hpp:25-116)
 // ---------------------------------------------------------------------------
-template <int D>
-__device__ __forceinline__ void source_sample(const TraceParams &p, Rng &rng, unsigned &t2, V3 &org, V3 &dir) {
+// `draw()` returns the next raw 64-bit engine output
+template <int D, bool HALF, class Draw>
+__device__ __forceinline__ void source_sample(const TraceParams &p, Draw &&draw, V3 &org, V3 &dir) {
   // origin draws first (raySourceRandom.hpp:50-68)
   org = mk(0.f, 0.f, 0.f);
-  const float r1 = canon_f32(rng_next(rng, t2));
+  const float r1 = canon_f32(draw());
   setc(org, p.rayDir, p.srcCoord);
   setc(org, p.firstDir, p.lo1 + (p.hi1 - p.lo1) * r1);
   if (D == 2) {
     setc(org, p.secondDir, 0.f);
   } else {
-    const float r2 = canon_f32(rng_next(rng, t2));
+    const float r2 = canon_f32(draw());
     setc(org, p.secondDir, p.lo2 + (p.hi2 - p.lo2) * r2);
   }
   // then the direction draws (raySourceRandom.hpp:70-116)
   if (!p.useBasis) {
-    const float d1 = canon_f32(rng_next(rng, t2));
-    const float d2 = canon_f32(rng_next(rng, t2));
+    const float d1 = canon_f32(draw());
+    const float d2 = canon_f32(draw());
     float ct, st, cp, sp;
-    cosine_sample(d1, d2, p.ee, ct, st, cp, sp);
+    cosine_sample<HALF>(d1, d2, p.ee, ct, st, cp, sp);
     dir = mk(0.f, 0.f, 0.f);
     setc(dir, p.rayDir, p.posNeg * ct);
     setc(dir, p.firstDir, cp * st);
@@ -59,10 +60,10 @@ __device__ __forceinline__ void source_sample(const TraceParams &p, Rng &rng, un
   } else {
     float dr;
     do {
-      const float d1 = canon_f32(rng_next(rng, t2));
-      const float d2 = canon_f32(rng_next(rng, t2));
+      const float d1 = canon_f32(draw());
+      const float d2 = canon_f32(draw());
       float ct, st, cp, sp;
-      cosine_sample(d1, d2, p.ee, ct, st, cp, sp);
+      cosine_sample<HALF>(d1, d2, p.ee, ct, st, cp, sp);
       const float a = ct, b = cp * st, c = sp * st;
       dir.x = (p.basis[0] * a + p.basis[3] * b) + p.basis[6] * c;
       dir.y = (p.basis[1] * a + p.basis[4] * b) + p.basis[7] * c;
@@ -117,31 +118,58 @@ template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p
 // gen_kernel: ray index -> ray record
 // ---------------------------------------------------------------------------
 template <int D, int NPRE>
+__device__ __forceinline__ void gen_store(const TraceParams &p, unsigned i, const V3 &o, const V3 &d, unsigned k) {
+  reinterpret_cast<float4 *>(p.genA)[i] = make_float4(o.x, o.y, o.z, d.x);
+  reinterpret_cast<float4 *>(p.genB)[i] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(k));
+  if (p.genBin) {
+    const unsigned b = bin_of<D>(p, o, project_dir<D>(d));
+    p.genBin[i] = b;
+    atomicAdd(&p.binHist[b], 1u);
+  }
+}
+
+// Fixed number of source draws (no tilted primary direction): the K = draws +
+// NPRE engine outputs a ray needs are produced straight into registers — no LDS
+// tape, no tier 2 — by one 156+K-step pass of the seeding recurrence.
+template <int D, int NPRE, bool HALF>
 __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
+  constexpr int NS = D == 3 ? 4 : 3;
+  constexpr int K = NS + NPRE;
+  for (unsigned i = blockIdx.x * VR_BLOCK + threadIdx.x; i < p.batchCount; i += gridDim.x * VR_BLOCK) {
+    const unsigned long long idx = p.idxList ? p.idxList[i] : p.batchFirst + i;
+    u64 out[K];
+    mt_first_outputs<K>(tea3((unsigned)idx, p.seed), out);
+    int k = 0;
+    V3 o, d;
+    source_sample<D, HALF>(p, [&]() { return out[k++]; }, o, d); // k is a compile-time sequence after unrolling
+    gen_store<D, NPRE>(p, i, o, d, (unsigned)NS);
+    if (NPRE > 0) {
+#pragma unroll
+      for (int s = 0; s < NPRE; ++s)
+        p.genTape[(size_t)s * p.batchCap + i] = out[NS + s];
+    }
+  }
+}
+
+// General generator (tilted primary direction: the rejection loop makes the number
+// of draws data dependent): LDS tape of the first VR_TAPE outputs + tier 2.
+template <int D, int NPRE> __global__ __launch_bounds__(VR_BLOCK) void gen_basis_kernel(const TraceParams p) {
   __shared__ u64 tape[VR_TAPE * VR_BLOCK];
   const unsigned tid = threadIdx.x;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6; // physical wave of this (bounded) grid
   u64 *scratchLane = p.rngScratch + (size_t)gwave * (312u * 64u) + (tid & 63u);
-  float4 *A = reinterpret_cast<float4 *>(p.genA);
-  float4 *B = reinterpret_cast<float4 *>(p.genB);
   for (unsigned i = blockIdx.x * VR_BLOCK + tid; i < p.batchCount; i += gridDim.x * VR_BLOCK) {
     const unsigned long long idx = p.idxList ? p.idxList[i] : p.batchFirst + i;
     Rng rng;
     rng_init(rng, tea3((unsigned)idx, p.seed), tape + tid, scratchLane);
     unsigned t2 = 0;
     V3 o, d;
-    source_sample<D>(p, rng, t2, o, d);
-    A[i] = make_float4(o.x, o.y, o.z, d.x);
-    B[i] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(rng.k));
+    source_sample<D, false>(p, [&]() { return rng_next(rng, t2); }, o, d);
+    gen_store<D, NPRE>(p, i, o, d, rng.k);
     if (NPRE > 0) {
 #pragma unroll
       for (int s = 0; s < NPRE; ++s)
         p.genTape[(size_t)s * p.batchCap + i] = rng_next(rng, t2);
-    }
-    if (p.genBin) {
-      const unsigned b = bin_of<D>(p, o, project_dir<D>(d));
-      p.genBin[i] = b;
-      atomicAdd(&p.binHist[b], 1u);
     }
   }
 }
@@ -500,16 +528,21 @@ hipError_t launch_gen(const TraceParams &p, int D, bool withTape, unsigned maxBl
     return hipSuccess;
   if (grid > maxBlocks)
     grid = maxBlocks; // grid-stride; bounds the tier-2 slabs to grid waves
-  if (D == 2) {
-    if (withTape)
-      hipLaunchKernelGGL((gen_kernel<2, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
-    else
-      hipLaunchKernelGGL((gen_kernel<2, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
-  } else {
-    if (withTape)
-      hipLaunchKernelGGL((gen_kernel<3, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
-    else
-      hipLaunchKernelGGL((gen_kernel<3, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  const bool half = p.ee == 0.5f;
+  const int key = (p.useBasis ? 8 : (half ? 4 : 0)) | (D == 2 ? 0 : 2) | (withTape ? 1 : 0);
+  switch (key) {
+  case 0: hipLaunchKernelGGL((gen_kernel<2, 0, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 1: hipLaunchKernelGGL((gen_kernel<2, VR_NPRE, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 2: hipLaunchKernelGGL((gen_kernel<3, 0, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 3: hipLaunchKernelGGL((gen_kernel<3, VR_NPRE, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 4: hipLaunchKernelGGL((gen_kernel<2, 0, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 5: hipLaunchKernelGGL((gen_kernel<2, VR_NPRE, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 6: hipLaunchKernelGGL((gen_kernel<3, 0, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 7: hipLaunchKernelGGL((gen_kernel<3, VR_NPRE, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 8: hipLaunchKernelGGL((gen_basis_kernel<2, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 9: hipLaunchKernelGGL((gen_basis_kernel<2, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 10: hipLaunchKernelGGL((gen_basis_kernel<3, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  default: hipLaunchKernelGGL((gen_basis_kernel<3, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
   }
   return hipGetLastError();
 }
