@@ -658,10 +658,8 @@ int vr_apply_prepare(vr_context *c) {
     cap = (uint32_t)std::min<uint64_t>(span, std::max<long long>(256, std::atoll(e)));
   cap = std::max<uint32_t>(cap, 1u);
   if (cap > c->batchCap || (!c->absorb && c->dGenTape.cap < (size_t)cap * VR_NPRE)) {
-    VR_HIP(c, c->dGenA.ensure((size_t)cap * 4));
-    VR_HIP(c, c->dGenB.ensure((size_t)cap * 4));
-    VR_HIP(c, c->dRayA.ensure((size_t)cap * 4));
-    VR_HIP(c, c->dRayB.ensure((size_t)cap * 4));
+    VR_HIP(c, c->dGenA.ensure((size_t)cap * 8)); // 32-byte records
+    VR_HIP(c, c->dRayA.ensure((size_t)cap * 8));
     VR_HIP(c, c->dGenBin.ensure(cap));
     if (!c->absorb) {
       VR_HIP(c, c->dGenTape.ensure((size_t)cap * VR_NPRE));
@@ -1101,15 +1099,17 @@ int vr_debug_source_sample(vr_context *c, const uint64_t *idx, uint32_t n, uint3
   VR_HIP(c, launch_gen(p, c->geo.D, false, (unsigned)c->numCUs * 8u, c->stream));
   VR_HIP(c, hipStreamSynchronize(c->stream));
   std::vector<float> A((size_t)n * 4), B((size_t)n * 4);
-  VR_HIP(c, hipMemcpy(A.data(), c->dGenA.p, (size_t)n * 16, hipMemcpyDeviceToHost));
-  VR_HIP(c, hipMemcpy(B.data(), c->dGenB.p, (size_t)n * 16, hipMemcpyDeviceToHost));
+  A.resize((size_t)n * 8);
+  VR_HIP(c, hipMemcpy(A.data(), c->dGenA.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+  (void)B;
   for (uint32_t i = 0; i < n; ++i) {
-    org[3 * i] = A[4 * (size_t)i];
-    org[3 * i + 1] = A[4 * (size_t)i + 1];
-    org[3 * i + 2] = A[4 * (size_t)i + 2];
-    dir[3 * i] = A[4 * (size_t)i + 3];
-    dir[3 * i + 1] = B[4 * (size_t)i];
-    dir[3 * i + 2] = B[4 * (size_t)i + 1];
+    const float *r = &A[8 * (size_t)i];
+    org[3 * i] = r[0];
+    org[3 * i + 1] = r[1];
+    org[3 * i + 2] = r[2];
+    dir[3 * i] = r[3];
+    dir[3 * i + 1] = r[4];
+    dir[3 * i + 2] = r[5];
   }
   dI.release();
   return VR_OK;

@@ -119,8 +119,9 @@ template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p
 // ---------------------------------------------------------------------------
 template <int D, int NPRE>
 __device__ __forceinline__ void gen_store(const TraceParams &p, unsigned i, const V3 &o, const V3 &d, unsigned k) {
-  reinterpret_cast<float4 *>(p.genA)[i] = make_float4(o.x, o.y, o.z, d.x);
-  reinterpret_cast<float4 *>(p.genB)[i] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(k));
+  float4 *rec = reinterpret_cast<float4 *>(p.genA) + 2 * (size_t)i; // 32-byte record {A, B}
+  rec[0] = make_float4(o.x, o.y, o.z, d.x);
+  rec[1] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(k));
   if (p.genBin) {
     const unsigned b = bin_of<D>(p, o, project_dir<D>(d));
     p.genBin[i] = b;
@@ -240,8 +241,11 @@ template <int NPRE> __global__ __launch_bounds__(VR_BLOCK) void scatter_kernel(c
     return;
   const unsigned b = p.genBin[i];
   const unsigned pos = p.binHist[b] + atomicAdd(&p.binCursor[b], 1u);
-  reinterpret_cast<float4 *>(p.rayA)[pos] = reinterpret_cast<const float4 *>(p.genA)[i];
-  reinterpret_cast<float4 *>(p.rayB)[pos] = reinterpret_cast<const float4 *>(p.genB)[i];
+  const float4 *src = reinterpret_cast<const float4 *>(p.genA) + 2 * (size_t)i;
+  float4 *dst = reinterpret_cast<float4 *>(p.rayA) + 2 * (size_t)pos;
+  const float4 ra = src[0], rb = src[1];
+  dst[0] = ra; // one 32-byte record: the two stores hit the same half cache line
+  dst[1] = rb;
   if (NPRE > 0) {
 #pragma unroll
     for (int s = 0; s < NPRE; ++s)
@@ -302,8 +306,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
   __syncthreads();
 
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
-  const float4 *__restrict__ rayA = reinterpret_cast<const float4 *>(p.rayA);
-  const float4 *__restrict__ rayB = reinterpret_cast<const float4 *>(p.rayB);
+  const float4 *__restrict__ rayAB = reinterpret_cast<const float4 *>(p.rayA);
   const float tnear = 1e-4f; // rayUtil.hpp:229-231
 
   // per-lane ray state
@@ -352,8 +355,8 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
       const unsigned avail = waveEnd - waveNext;
       if (!active && rank < avail) {
         const unsigned j = waveNext + rank;
-        const float4 a = rayA[j];
-        const float4 b = rayB[j];
+        const float4 a = rayAB[2 * (size_t)j];
+        const float4 b = rayAB[2 * (size_t)j + 1];
         org = mk(a.x, a.y, a.z);
         rayDirection = mk(a.w, b.x, b.y);
         dir = project_dir<D>(rayDirection); // what Embree sees (rayUtil.hpp:204-227)

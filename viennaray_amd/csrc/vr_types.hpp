@@ -27,7 +27,7 @@ struct Tri {       // boundary wall triangle, Embree's precomputed form
 };
 
 // Ray stream record (HBM-resident, sorted by source-plane cell before tracing):
-//   A = {org.x, org.y, org.z, dir.x}   B = {dir.y, dir.z, bits(idx - batchFirst), bits(k)}
+//   32 B: A = {org.x, org.y, org.z, dir.x}   B = {dir.y, dir.z, bits(idx - batchFirst), bits(k)}
 //   k = number of engine outputs the source sampling consumed
 //   tape[s][i] (only for particles that keep going after a hit): raw engine
 //   outputs k .. k+VR_NPRE-1 of ray i, structure-of-arrays by slot
@@ -50,10 +50,10 @@ struct TraceParams {
   unsigned long long *workCounter;
   unsigned long long *rngScratch; // [waves][312][64]
   // ray stream of the current batch
-  float *genA, *genB;             // unsorted, float4 per ray
+  float *genA, *genB;             // unsorted 32-byte records {A,B} in genA (genB unused)
   unsigned long long *genTape;    // [VR_NPRE][batchCap] or nullptr
   uint32_t *genBin;               // bin of each unsorted ray
-  float *rayA, *rayB;             // sorted
+  float *rayA, *rayB;             // sorted 32-byte records in rayA (rayB unused)
   unsigned long long *rayTape;
   uint32_t *binHist;              // [numBins] counts -> exclusive starts
   uint32_t *binCursor;            // [numBins]
