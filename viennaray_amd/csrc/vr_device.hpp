@@ -263,16 +263,15 @@ __device__ __forceinline__ bool wall_reachable(float W, float oa, float da) {
   return (c > 0.f && da > 0.f) || (c < 0.f && da < 0.f);
 }
 
-template <int GEO>
-__device__ __forceinline__ void closest_hit(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
-                                            const V3 &d, float tnear, HitRec &h) {
+// boundary: 8 wall triangles {v0,e1,e2,Ng} in LDS; pairs (0,1) (2,3) lie on the
+// firstDir min/max planes, (4,5) (6,7) on the secondDir min/max planes
+__device__ __forceinline__ void hit_init_walls(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
+                                               const V3 &d, float tnear, HitRec &h) {
   h.t = 3.402823466e+38f;
   h.geom = -1;
   h.prim = 0xFFFFFFFFu;
   h.pos = 0;
-  // boundary: 8 wall triangles {v0,e1,e2,Ng} in LDS; pairs (0,1) (2,3) lie on the
-  // firstDir min/max planes, (4,5) (6,7) on the secondDir min/max planes
-  {
+  if (!(p.debugFlags & 8u)) {
     const float o1 = getc(o, p.firstDir), d1 = getc(d, p.firstDir);
     const float o2 = getc(o, p.secondDir), d2 = getc(d, p.secondDir);
 #pragma unroll
@@ -297,18 +296,33 @@ __device__ __forceinline__ void closest_hit(const TraceParams &p, const float *_
       }
     }
   }
+}
+
+__device__ __forceinline__ V3 safe_inverse(const V3 &d) {
+  const float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
+  const float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
+  const float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
+  return V3{1.0f / dx, 1.0f / dy, 1.0f / dz};
+}
+
+// closest-hit rule: min t; ties -> boundary first, then lower original id
+__device__ __forceinline__ void hit_update(HitRec &h, bool ok, float t, unsigned orig, unsigned q) {
+  if (ok && (t < h.t || (t == h.t && h.geom == 1 && orig < h.prim))) {
+    h.t = t;
+    h.geom = 1;
+    h.prim = orig;
+    h.pos = q;
+  }
+}
+
+// geometry, per-lane: every lane walks its own path (incoherent rays)
+template <int GEO>
+__device__ __forceinline__ void bvh_hit_lane(const TraceParams &p, const V3 &o, const V3 &d, float tnear, HitRec &h) {
   if (p.numPrims == 0)
     return;
-  // geometry: stackless escape-link traversal
   const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(p.nodes);
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
-  V3 inv;
-  {
-    float dx = fabsf(d.x) < 1e-30f ? copysignf(1e-30f, d.x) : d.x;
-    float dy = fabsf(d.y) < 1e-30f ? copysignf(1e-30f, d.y) : d.y;
-    float dz = fabsf(d.z) < 1e-30f ? copysignf(1e-30f, d.z) : d.z;
-    inv = V3{1.0f / dx, 1.0f / dy, 1.0f / dz};
-  }
+  const V3 inv = safe_inverse(d);
   const V3 oi = V3{o.x * inv.x, o.y * inv.y, o.z * inv.z};
   unsigned node = 0;
   while (node != VR_END) {
@@ -329,24 +343,16 @@ __device__ __forceinline__ void closest_hit(const TraceParams &p, const float *_
         for (unsigned i = 0; i < cnt; ++i) {
           const unsigned q = first + i;
           float t;
-          unsigned orig;
-          bool ok;
           if (GEO == 0) {
             const float4 c4 = prims[2 * q];
             const float4 n4 = prims[2 * q + 1];
-            orig = __float_as_uint(n4.w);
-            ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
+            const bool ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
+            hit_update(h, ok, t, __float_as_uint(n4.w), q);
           } else {
             const float4 a = prims[4 * q], b = prims[4 * q + 1], c = prims[4 * q + 2], e = prims[4 * q + 3];
-            orig = __float_as_uint(a.w);
-            ok = hit_tri(o, d, tnear, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(e.x, e.y, e.z), t);
-          }
-          // closest-hit rule: min t; ties -> boundary first, then lower original id
-          if (ok && (t < h.t || (t == h.t && h.geom == 1 && orig < h.prim))) {
-            h.t = t;
-            h.geom = 1;
-            h.prim = orig;
-            h.pos = q;
+            const bool ok =
+                hit_tri(o, d, tnear, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(e.x, e.y, e.z), t);
+            hit_update(h, ok, t, __float_as_uint(a.w), q);
           }
         }
         node = esc;
@@ -357,6 +363,72 @@ __device__ __forceinline__ void closest_hit(const TraceParams &p, const float *_
       node = esc;
     }
   }
+}
+
+// geometry, wave-uniform ("packet"): the 64 rays of a wavefront that were sorted
+// into the same far-plane cell walk the UNION of their paths in lock step.  The
+// node index is a scalar, node and primitive records come through the scalar
+// cache (s_load, constant address space) instead of 64 per-lane vector loads,
+// and there is no per-lane exec masking inside the traversal.  A lane that
+// misses a box still runs the subtree's primitive tests; those are exact, so the
+// selected hit is unchanged (the box test only ever culls).
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef const vf4 __attribute__((address_space(4))) *ConstF4;
+
+template <int GEO>
+__device__ __forceinline__ void bvh_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
+                                               HitRec &h) {
+  if (p.numPrims == 0)
+    return;
+  ConstF4 nodes = (ConstF4)(p.nodes);
+  ConstF4 prims = (ConstF4)(p.prims);
+  const V3 inv = safe_inverse(d);
+  const V3 oi = V3{o.x * inv.x, o.y * inv.y, o.z * inv.z};
+  unsigned node = 0; // wave-uniform
+  while (node != VR_END) {
+    const vf4 q0 = nodes[2 * node];
+    const vf4 q1 = nodes[2 * node + 1];
+    const float tx0 = __builtin_fmaf(q0.x, inv.x, -oi.x), tx1 = __builtin_fmaf(q1.x, inv.x, -oi.x);
+    const float ty0 = __builtin_fmaf(q0.y, inv.y, -oi.y), ty1 = __builtin_fmaf(q1.y, inv.y, -oi.y);
+    const float tz0 = __builtin_fmaf(q0.z, inv.z, -oi.z), tz1 = __builtin_fmaf(q1.z, inv.z, -oi.z);
+    const float tEntry = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
+    const float tExit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), h.t));
+    const unsigned link = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
+    const unsigned esc = __builtin_amdgcn_readfirstlane(__float_as_uint(q1.w));
+    if (__ballot(part && tEntry <= tExit)) {
+      if (link & VR_LEAF) {
+        const unsigned first = link & VR_LEAF_FIRST_MASK;
+        const unsigned cnt = (link >> 27) & 15u;
+        for (unsigned i = 0; i < cnt; ++i) {
+          const unsigned q = first + i;
+          float t;
+          if (GEO == 0) {
+            const vf4 c4v = prims[2 * q];
+            const vf4 n4 = prims[2 * q + 1];
+            const bool ok = hit_disc(o, d, tnear, make_float4(c4v.x, c4v.y, c4v.z, c4v.w), mk(n4.x, n4.y, n4.z), t);
+            hit_update(h, part && ok, t, __float_as_uint(n4.w), q);
+          } else {
+            const vf4 a = prims[4 * q], b = prims[4 * q + 1], c = prims[4 * q + 2], e = prims[4 * q + 3];
+            const bool ok =
+                hit_tri(o, d, tnear, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(e.x, e.y, e.z), t);
+            hit_update(h, part && ok, t, __float_as_uint(a.w), q);
+          }
+        }
+        node = esc;
+      } else {
+        node = link;
+      }
+    } else {
+      node = esc;
+    }
+  }
+}
+
+template <int GEO>
+__device__ __forceinline__ void closest_hit(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
+                                            const V3 &d, float tnear, HitRec &h) {
+  hit_init_walls(p, wallS, o, d, tnear, h);
+  bvh_hit_lane<GEO>(p, o, d, tnear, h);
 }
 
 // rayTraceKernel.hpp:462-507 (neighbour disk test)

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
   float rayWeight = 0.f;
   unsigned numReflections = 0, boundaryHits = 0;
   bool hitFromBack = false;
+  bool fresh = false; // first segment of a ray pulled from the sorted stream
   Rng rng;
   rng.tape = tape + tid;
   rng.scratch = p.rngScratch + (size_t)gwave * (312u * 64u) + lane;
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
         numReflections = 0;
         boundaryHits = 0;
         hitFromBack = false;
+        fresh = true;
         active = true;
         if (!ABSORB) {
           const unsigned idxOff = __float_as_uint(b.z);
@@ -381,10 +383,22 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
     if (!__ballot(active))
       break;
 
+    // ---- closest hit of one trace segment (rtcIntersect1, rayTraceKernel.hpp:163-167) ----
+    // Rays that were just pulled from the sorted stream are coherent: they take the
+    // wave-uniform packet traversal.  Continuing rays (after a wall or a bounce)
+    // have scattered: per-lane traversal.
+    HitRec h;
+    hit_init_walls(p, wallS, org, dir, tnear, h); // (idle lanes compute on stale values; unused)
+    const bool packetLane = active && fresh;
+    const bool usePacket = !(p.debugFlags & 32u) && __popcll(__ballot(packetLane)) >= 8;
+    if (usePacket)
+      bvh_hit_packet<GEO>(p, packetLane, org, dir, tnear, h);
+    if (active && !(usePacket && fresh))
+      bvh_hit_lane<GEO>(p, org, dir, tnear, h);
+    fresh = false;
+
     if (active) {
-      // ---- one trace segment (rayTraceKernel.hpp:155-335) ----
-      HitRec h;
-      closest_hit<GEO>(p, wallS, org, dir, tnear, h);
+      // ---- the reference's state machine for this segment (rayTraceKernel.hpp:169-335) ----
       ++cTraces;
       if (h.geom < 0) { // miss, :172-176
         ++cNongeo;
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
             const u64 wfx = weight_fx(rayWeight);
             if (!(p.debugFlags & 1u))
               atomicAdd(&p.fluxAcc[h.pos], wfx); // surfaceCollision, rayParticle.hpp:148-156
-            if (GEO == 0) {
+            if (GEO == 0 && !(p.debugFlags & 4u)) {
               // every overlapping neighbour disk is credited the full weight (:271-300)
               const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
               for (unsigned j = nb; j < ne; ++j) {
