@@ -754,6 +754,15 @@ int vr_apply_prepare(vr_context *c) {
   p.hi1 = c->bbHi[c->ts[1]];
   p.lo2 = c->bbLo[c->ts[2]];
   p.hi2 = c->bbHi[c->ts[2]];
+  {
+    const float lr = c->bbLo[c->ts[0]], hr = c->bbHi[c->ts[0]];
+    float scale = 0.f;
+    for (int k = 0; k < 3; ++k)
+      scale = std::max(scale, std::max(std::fabs(c->bbLo[k]), std::fabs(c->bbHi[k])));
+    const float margin = 1e-3f * std::max(scale, hr - lr) + 1e-6f;
+    p.wallLoR = lr - margin;
+    p.wallHiR = hr + margin;
+  }
   p.farCoord = c->ts[3] ? c->geo.minC[c->ts[0]] : c->geo.maxC[c->ts[0]];
   p.invExt1 = (p.hi1 > p.lo1) ? 1.f / (p.hi1 - p.lo1) : 0.f;
   p.invExt2 = (p.hi2 > p.lo2) ? 1.f / (p.hi2 - p.lo2) : 0.f;

@@ -279,8 +279,18 @@ __device__ __forceinline__ void hit_init_walls(const TraceParams &p, const float
       const float *w0 = wallS + 24 * pair;
       const int axis = pair < 2 ? p.firstDir : p.secondDir;
       const float W = axis == 0 ? w0[0] : (axis == 1 ? w0[1] : w0[2]);
-      if (!wall_reachable(W, pair < 2 ? o1 : o2, pair < 2 ? d1 : d2))
+      const float oa = pair < 2 ? o1 : o2, da = pair < 2 ? d1 : d2;
+      if (!wall_reachable(W, oa, da))
         continue;
+      {
+        // conservative rectangle pre-test: where the ray meets the wall plane it must lie
+        // inside the wall's extent along the tracing axis (the walls span the whole
+        // adjusted bbox there), up to a margin far above the rounding of either test
+        const float tw = (W - oa) / da;
+        const float cr = getc(o, p.rayDir) + getc(d, p.rayDir) * tw;
+        if (cr < p.wallLoR || cr > p.wallHiR)
+          continue;
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const float *w = w0 + 12 * j;

@@ -281,6 +281,25 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
   return s;
 }
 
+// Credit `wfx` to accumulator `pos` for every lane with `cond`; lanes of the wave that
+// credit the same accumulator with the same weight are merged into one atomic
+// (sorted rays: a wavefront's hits fall on a handful of disks).
+__device__ __forceinline__ void credit_aggregated(unsigned long long *acc, bool cond, unsigned pos, u64 wfx) {
+  unsigned long long todo = __ballot(cond);
+  const unsigned lane = threadIdx.x & 63u;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const unsigned P = __shfl(pos, leader, 64);
+    const unsigned wlo = __shfl((unsigned)(wfx & 0xFFFFFFFFull), leader, 64);
+    const unsigned whi = __shfl((unsigned)(wfx >> 32), leader, 64);
+    const u64 W = ((u64)whi << 32) | wlo;
+    const unsigned long long same = __ballot(cond && pos == P && wfx == W);
+    if ((int)lane == leader)
+      atomicAdd(&acc[P], W * (u64)__popcll(same));
+    todo &= ~same;
+  }
+}
+
 __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xFFFFFFFFull));
   unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -462,8 +481,13 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
           } else {
             ++cGeo;
             const u64 wfx = weight_fx(rayWeight);
-            if (!(p.debugFlags & 1u))
-              atomicAdd(&p.fluxAcc[h.pos], wfx); // surfaceCollision, rayParticle.hpp:148-156
+            // surfaceCollision, rayParticle.hpp:148-156
+            if (!(p.debugFlags & 1u)) {
+              if (usePacket)
+                credit_aggregated(p.fluxAcc, true, h.pos, wfx);
+              else
+                atomicAdd(&p.fluxAcc[h.pos], wfx);
+            }
             if (GEO == 0 && !(p.debugFlags & 4u)) {
               // every overlapping neighbour disk is credited the full weight (:271-300)
               const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
@@ -471,7 +495,10 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
                 const unsigned q = p.nbIds[j];
                 const float4 c4 = prims[2 * q];
                 const float4 n4 = prims[2 * q + 1];
-                if (local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u))
+                const bool hitN = local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u);
+                if (usePacket)
+                  credit_aggregated(p.fluxAcc, hitN, q, wfx);
+                else if (hitN)
                   atomicAdd(&p.fluxAcc[q], wfx);
               }
             }

@@ -74,6 +74,7 @@ struct TraceParams {
   // adjusted bounding box, as scalars (no dynamic indexing of kernel arguments)
   float srcCoord;                 // origin[rayDir]
   float lo1, hi1, lo2, hi2;       // extents along firstDir / secondDir
+  float wallLoR, wallHiR;         // wall extent along rayDir, widened by a safety margin
   // sort-key binning (far-plane crossing cell)
   float farCoord;                 // geometry bbox face opposite the source, on rayDir
   float invExt1, invExt2;         // 1 / (hi - lo) along firstDir / secondDir (0 if degenerate)
