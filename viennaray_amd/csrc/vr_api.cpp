@@ -48,6 +48,7 @@ struct vr_context {
   int device = 0;
   int numCUs = 256;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr; // generator / sorter stream (overlaps the tracer)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
 
@@ -101,8 +102,10 @@ struct vr_context {
   bool hostOrderValid = false;   // c->bvh.order mirrors dOrder
   bool hostNeighborsValid = false;
   // ray stream (one batch)
-  DevBuf<float> dGenA, dGenB, dRayA, dRayB, dWalls;
-  DevBuf<unsigned long long> dGenTape, dRayTape;
+  DevBuf<float> dGenA, dGenB, dRayA, dRayB, dRayA2, dWalls;
+  DevBuf<unsigned long long> dGenTape, dRayTape, dRayTape2;
+  std::vector<hipEvent_t> evSort, evTraced; // per batch: sorted stream ready / trace finished
+  bool overlap = false;
   DevBuf<uint32_t> dGenBin, dBinHist, dBinCursor, dScanTmp;
   uint32_t batchCap = 0;      // rays per batch the buffers hold
   uint32_t numBins = 0;
@@ -152,6 +155,7 @@ int vr_create(vr_context **out, int device) {
   vr_context *c = new vr_context();
   c->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return VR_E_HIP;
@@ -169,6 +173,14 @@ void vr_destroy(vr_context *c) {
   (void)hipSetDevice(c->device);
   if (c->stream)
     (void)hipStreamSynchronize(c->stream);
+  if (c->stream2)
+    (void)hipStreamSynchronize(c->stream2);
+  c->dRayA2.release();
+  c->dRayTape2.release();
+  for (auto e : c->evSort)
+    (void)hipEventDestroy(e);
+  for (auto e : c->evTraced)
+    (void)hipEventDestroy(e);
   c->dNodes.release();
   c->dPrims.release();
   c->dPrimSticking.release();
@@ -198,6 +210,8 @@ void vr_destroy(vr_context *c) {
     (void)hipEventDestroy(c->ev1);
   if (c->stream)
     (void)hipStreamDestroy(c->stream);
+  if (c->stream2)
+    (void)hipStreamDestroy(c->stream2);
   delete c;
 }
 
@@ -653,7 +667,9 @@ int vr_apply_prepare(vr_context *c) {
 
   // ---- ray-stream buffers: batches of up to 2^25 rays --------------------------
   const uint64_t span = last - first;
-  uint32_t cap = (uint32_t)std::min<uint64_t>(span, 1ull << 25);
+  // batches of up to 2^24 rays; with more than one batch the generator/sorter of batch
+  // b+1 runs on a second stream while batch b is traced (double-buffered sorted streams)
+  uint32_t cap = (uint32_t)std::min<uint64_t>(span, 1ull << 24);
   if (const char *e = std::getenv("VR_BATCH_RAYS"))
     cap = (uint32_t)std::min<uint64_t>(span, std::max<long long>(256, std::atoll(e)));
   cap = std::max<uint32_t>(cap, 1u);
@@ -666,6 +682,15 @@ int vr_apply_prepare(vr_context *c) {
       VR_HIP(c, c->dRayTape.ensure((size_t)cap * VR_NPRE));
     }
     c->batchCap = std::max(c->batchCap, cap);
+  }
+  c->overlap = span > c->batchCap;
+  if (const char *e = std::getenv("VR_NO_OVERLAP"))
+    if (std::atoi(e))
+      c->overlap = false;
+  if (c->overlap) {
+    VR_HIP(c, c->dRayA2.ensure((size_t)c->batchCap * 8));
+    if (!c->absorb)
+      VR_HIP(c, c->dRayTape2.ensure((size_t)c->batchCap * VR_NPRE));
   }
   // source-plane cells: about one per 32 rays of a batch, at most ~4 per primitive
   {
@@ -699,7 +724,14 @@ int vr_apply_prepare(vr_context *c) {
   }
 
   // launch geometry of the persistent kernels
-  c->grid = (unsigned)c->numCUs * (unsigned)std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->particleKind, c->absorb));
+  {
+    int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->particleKind, c->absorb));
+    if (c->overlap && blocks > 4)
+      blocks -= 2; // leave wave slots for the concurrently running generator / sorter
+    if (const char *e = std::getenv("VR_TRACE_BLOCKS"))
+      blocks = std::max(1, std::atoi(e));
+    c->grid = (unsigned)c->numCUs * (unsigned)blocks;
+  }
   const size_t waves = (size_t)std::max(c->grid, (unsigned)c->numCUs * 8u) * (VR_BLOCK / 64);
   if (waves > c->scratchWaves) {
     VR_HIP(c, c->dScratch.ensure(waves * 312u * 64u));
@@ -778,7 +810,7 @@ int vr_apply_prepare(vr_context *c) {
   return VR_OK;
 }
 
-// one batch of the ray stream: generate -> bin -> sort -> trace
+// one batch of the ray stream: generate -> bin -> sort (stream2 when overlapping) -> trace
 static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batchNo) {
   TraceParams p = c->params;
   p.batchFirst = first;
@@ -793,20 +825,44 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
     p.chunk = (uint32_t)chunk;
   }
   const bool tape = !c->absorb;
-  VR_HIP(c, hipMemsetAsync(c->dBinHist.p, 0, (size_t)c->numBins * 4, c->stream));
-  VR_HIP(c, hipMemsetAsync(c->dBinCursor.p, 0, (size_t)c->numBins * 4, c->stream));
-  VR_HIP(c, hipMemsetAsync(p.workCounter, 0, 8, c->stream));
-  VR_HIP(c, launch_gen(p, c->geo.D, tape, (unsigned)c->numCUs * 8u, c->stream));
-  VR_HIP(c, launch_scan(c->dBinHist.p, c->numBins, c->dScanTmp.p, c->stream));
-  VR_HIP(c, launch_scatter(p, tape, c->stream));
+  const unsigned slot = c->overlap ? (unsigned)(batchNo & 1) : 0u;
+  if (slot) {
+    p.rayA = c->dRayA2.p;
+    p.rayTape = tape ? c->dRayTape2.p : nullptr;
+  }
+  p.workCounter = c->dCounters.p + 8 + slot;
+  hipStream_t sg = c->overlap ? c->stream2 : c->stream;
   while (c->evK.size() < 2 * (batchNo + 1)) {
     hipEvent_t e;
     VR_HIP(c, hipEventCreate(&e));
     c->evK.push_back(e);
   }
+  while (c->evSort.size() <= batchNo) {
+    hipEvent_t e, f;
+    VR_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    VR_HIP(c, hipEventCreateWithFlags(&f, hipEventDisableTiming));
+    c->evSort.push_back(e);
+    c->evTraced.push_back(f);
+  }
+  // generator / sorter
+  VR_HIP(c, hipMemsetAsync(c->dBinHist.p, 0, (size_t)c->numBins * 4, sg));
+  VR_HIP(c, hipMemsetAsync(c->dBinCursor.p, 0, (size_t)c->numBins * 4, sg));
+  VR_HIP(c, launch_gen(p, c->geo.D, tape, (unsigned)c->numCUs * 8u, sg));
+  VR_HIP(c, launch_scan(c->dBinHist.p, c->numBins, c->dScanTmp.p, sg));
+  if (c->overlap && batchNo >= 2) // the sorted buffer of this slot is free once batch b-2 is traced
+    VR_HIP(c, hipStreamWaitEvent(sg, c->evTraced[batchNo - 2], 0));
+  VR_HIP(c, launch_scatter(p, tape, sg));
+  // tracer
+  if (c->overlap) {
+    VR_HIP(c, hipEventRecord(c->evSort[batchNo], sg));
+    VR_HIP(c, hipStreamWaitEvent(c->stream, c->evSort[batchNo], 0));
+  }
+  VR_HIP(c, hipMemsetAsync(p.workCounter, 0, 8, c->stream));
   VR_HIP(c, hipEventRecord(c->evK[2 * batchNo], c->stream));
   VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->particleKind, c->absorb, c->grid, c->stream));
   VR_HIP(c, hipEventRecord(c->evK[2 * batchNo + 1], c->stream));
+  if (c->overlap)
+    VR_HIP(c, hipEventRecord(c->evTraced[batchNo], c->stream));
   return VR_OK;
 }
 
@@ -820,6 +876,8 @@ int vr_apply_launch(vr_context *c) {
   VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)N * 8, c->stream));
   VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 16 * 8, c->stream));
   VR_HIP(c, hipEventRecord(c->ev0, c->stream));
+  if (c->overlap)
+    VR_HIP(c, hipStreamWaitEvent(c->stream2, c->ev0, 0));
   c->numBatches = 0;
   for (uint64_t f = c->rayFirstLaunch; f < c->rayEndLaunch; f += c->batchCap) {
     const uint32_t cnt = (uint32_t)std::min<uint64_t>(c->batchCap, c->rayEndLaunch - f);

@@ -277,8 +277,8 @@ __device__ __forceinline__ void hit_init_walls(const TraceParams &p, const float
 #pragma unroll
     for (int pair = 0; pair < 4; ++pair) {
       const float *w0 = wallS + 24 * pair;
-      const int axis = pair < 2 ? p.firstDir : p.secondDir;
-      const float W = axis == 0 ? w0[0] : (axis == 1 ? w0[1] : w0[2]);
+      // the wall planes are the adjusted bbox faces: scalars, no LDS read needed to cull
+      const float W = pair == 0 ? p.lo1 : (pair == 1 ? p.hi1 : (pair == 2 ? p.lo2 : p.hi2));
       const float oa = pair < 2 ? o1 : o2, da = pair < 2 ? d1 : d2;
       if (!wall_reachable(W, oa, da))
         continue;
@@ -286,7 +286,8 @@ __device__ __forceinline__ void hit_init_walls(const TraceParams &p, const float
         // conservative rectangle pre-test: where the ray meets the wall plane it must lie
         // inside the wall's extent along the tracing axis (the walls span the whole
         // adjusted bbox there), up to a margin far above the rounding of either test
-        const float tw = (W - oa) / da;
+        // (so the approximate reciprocal is fine)
+        const float tw = (W - oa) * __builtin_amdgcn_rcpf(da);
         const float cr = getc(o, p.rayDir) + getc(d, p.rayDir) * tw;
         if (cr < p.wallLoR || cr > p.wallHiR)
           continue;
