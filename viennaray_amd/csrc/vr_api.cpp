@@ -102,11 +102,13 @@ struct vr_context {
   bool hostOrderValid = false;   // c->bvh.order mirrors dOrder
   bool hostNeighborsValid = false;
   // ray stream (one batch)
-  DevBuf<float> dGenA, dGenB, dRayA, dRayB, dRayA2, dWalls;
-  DevBuf<unsigned long long> dGenTape, dRayTape, dRayTape2;
+  DevBuf<float> dSlotRec, dSlotRec2, dWalls;
+  DevBuf<unsigned long long> dSlotTape, dSlotTape2;
+  DevBuf<uint32_t> dBinCount, dBinCount2;
+  size_t slotStride = 0;
   std::vector<hipEvent_t> evSort, evTraced; // per batch: sorted stream ready / trace finished
   bool overlap = false;
-  DevBuf<uint32_t> dGenBin, dBinHist, dBinCursor, dScanTmp;
+  DevBuf<uint32_t> dScanTmp;
   uint32_t batchCap = 0;      // rays per batch the buffers hold
   uint32_t numBins = 0;
   uint64_t rayFirstLaunch = 0, rayEndLaunch = 0;
@@ -175,8 +177,6 @@ void vr_destroy(vr_context *c) {
     (void)hipStreamSynchronize(c->stream);
   if (c->stream2)
     (void)hipStreamSynchronize(c->stream2);
-  c->dRayA2.release();
-  c->dRayTape2.release();
   for (auto e : c->evSort)
     (void)hipEventDestroy(e);
   for (auto e : c->evTraced)
@@ -191,16 +191,13 @@ void vr_destroy(vr_context *c) {
   c->dFluxOrig.release();
   c->dCounters.release();
   c->dScratch.release();
-  c->dGenA.release();
-  c->dGenB.release();
-  c->dRayA.release();
-  c->dRayB.release();
   c->dWalls.release();
-  c->dGenTape.release();
-  c->dRayTape.release();
-  c->dGenBin.release();
-  c->dBinHist.release();
-  c->dBinCursor.release();
+  c->dSlotRec.release();
+  c->dSlotRec2.release();
+  c->dSlotTape.release();
+  c->dSlotTape2.release();
+  c->dBinCount.release();
+  c->dBinCount2.release();
   c->dScanTmp.release();
   for (auto e : c->evK)
     (void)hipEventDestroy(e);
@@ -665,62 +662,50 @@ int vr_apply_prepare(vr_context *c) {
   for (float v : c->matStickVals)
     c->absorb = c->absorb && v >= 1.f;
 
-  // ---- ray-stream buffers: batches of up to 2^25 rays --------------------------
+  // ---- ray stream: one batch of up to 2^27 rays; larger launches run several batches and
+  // overlap the generator of batch b+1 (second stream) with the tracer of batch b ----------
   const uint64_t span = last - first;
-  // batches of up to 2^24 rays; with more than one batch the generator/sorter of batch
-  // b+1 runs on a second stream while batch b is traced (double-buffered sorted streams)
-  uint32_t cap = (uint32_t)std::min<uint64_t>(span, 1ull << 24);
+  uint32_t cap = (uint32_t)std::min<uint64_t>(span, 1ull << 27);
   if (const char *e = std::getenv("VR_BATCH_RAYS"))
     cap = (uint32_t)std::min<uint64_t>(span, std::max<long long>(256, std::atoll(e)));
   cap = std::max<uint32_t>(cap, 1u);
-  if (cap > c->batchCap || (!c->absorb && c->dGenTape.cap < (size_t)cap * VR_NPRE)) {
-    VR_HIP(c, c->dGenA.ensure((size_t)cap * 8)); // 32-byte records
-    VR_HIP(c, c->dRayA.ensure((size_t)cap * 8));
-    VR_HIP(c, c->dGenBin.ensure(cap));
-    if (!c->absorb) {
-      VR_HIP(c, c->dGenTape.ensure((size_t)cap * VR_NPRE));
-      VR_HIP(c, c->dRayTape.ensure((size_t)cap * VR_NPRE));
-    }
-    c->batchCap = std::max(c->batchCap, cap);
-  }
-  c->overlap = span > c->batchCap;
+  c->batchCap = cap;
+  c->overlap = span > cap;
   if (const char *e = std::getenv("VR_NO_OVERLAP"))
     if (std::atoi(e))
       c->overlap = false;
-  if (c->overlap) {
-    VR_HIP(c, c->dRayA2.ensure((size_t)c->batchCap * 8));
-    if (!c->absorb)
-      VR_HIP(c, c->dRayTape2.ensure((size_t)c->batchCap * VR_NPRE));
-  }
-  // source-plane cells: about one per 32 rays of a batch, at most ~4 per primitive
+  // sort bins: far-plane cells holding ~32 rays each (half a wavefront), VR_BIN_CAP slots
   {
-    uint64_t target = std::min<uint64_t>({(uint64_t)4 * N, std::max<uint64_t>(cap / 32, 1), 1ull << 22});
-    int T1, T2;
-    if (D == 2) {
-      T1 = (int)std::min<uint64_t>(std::max<uint64_t>(target, 1), 1u << 20);
-      T2 = 1;
-    } else {
-      T1 = T2 = (int)std::min<double>(2048.0, std::max(1.0, std::ceil(std::sqrt((double)target))));
-    }
-    if (const char *e = std::getenv("VR_BINS_PER_AXIS")) {
-      T1 = std::max(1, std::min(D == 2 ? (1 << 20) : 2048, std::atoi(e)));
-      T2 = D == 2 ? 1 : T1;
-    }
+    uint64_t target = std::max<uint64_t>(cap / 32, 1);
+    int T1, T2, tiles = 1;
+    if (const char *e = std::getenv("VR_RAYS_PER_BIN"))
+      target = std::max<uint64_t>(cap / std::max(1, std::atoi(e)), 1);
     uint32_t nb;
     if (D == 2) {
+      T1 = (int)std::min<uint64_t>(target, 1u << 22);
+      T2 = 1;
       nb = (uint32_t)T1;
     } else {
-      uint32_t P = 1;
-      while ((int)P < std::max(T1, T2))
-        P <<= 1;
-      nb = P * P;
+      T1 = T2 = (int)std::min<double>(4096.0, std::max(1.0, std::ceil(std::sqrt((double)target))));
+      tiles = (T1 + 7) / 8;
+      nb = (uint32_t)tiles * (uint32_t)tiles * 64u;
     }
     c->numBins = nb;
     p.binT1 = T1;
     p.binT2 = T2;
-    VR_HIP(c, c->dBinHist.ensure(nb));
-    VR_HIP(c, c->dBinCursor.ensure(nb));
-    VR_HIP(c, c->dScanTmp.ensure(2 * ((size_t)nb / 2048 + 2) + 16));
+    p.binTiles = tiles;
+    const size_t slots = (size_t)nb * VR_BIN_CAP + cap; // bins + overflow region
+    c->slotStride = slots;
+    VR_HIP(c, c->dSlotRec.ensure(slots * 8));
+    VR_HIP(c, c->dBinCount.ensure((size_t)nb + 1));
+    if (!c->absorb)
+      VR_HIP(c, c->dSlotTape.ensure(slots * VR_NPRE));
+    if (c->overlap) {
+      VR_HIP(c, c->dSlotRec2.ensure(slots * 8));
+      VR_HIP(c, c->dBinCount2.ensure((size_t)nb + 1));
+      if (!c->absorb)
+        VR_HIP(c, c->dSlotTape2.ensure(slots * VR_NPRE));
+    }
   }
 
   // launch geometry of the persistent kernels
@@ -748,19 +733,14 @@ int vr_apply_prepare(vr_context *c) {
   p.counters = c->dCounters.p;
   p.workCounter = c->dCounters.p + 8;
   p.rngScratch = c->dScratch.p;
-  p.genA = c->dGenA.p;
-  p.genB = c->dGenB.p;
-  p.genTape = c->absorb ? nullptr : c->dGenTape.p;
-  p.genBin = c->dGenBin.p;
-  p.rayA = c->dRayA.p;
-  p.rayB = c->dRayB.p;
-  p.rayTape = c->absorb ? nullptr : c->dRayTape.p;
-  p.binHist = c->dBinHist.p;
-  p.binCursor = c->dBinCursor.p;
+  p.slotRec = c->dSlotRec.p;
+  p.slotTape = c->absorb ? nullptr : c->dSlotTape.p;
+  p.binCount = c->dBinCount.p;
   p.idxList = nullptr;
   p.batchFirst = first;
   p.batchCount = 0;
-  p.batchCap = c->batchCap;
+  p.slotStride = (uint32_t)c->slotStride;
+  p.ovCap = c->batchCap;
   p.numBins = c->numBins;
   p.seed = seed;
   p.numPrims = N;
@@ -810,25 +790,19 @@ int vr_apply_prepare(vr_context *c) {
   return VR_OK;
 }
 
-// one batch of the ray stream: generate -> bin -> sort (stream2 when overlapping) -> trace
+// one batch of the ray stream: generate straight into the sort bins (stream2 when
+// overlapping), then trace
 static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batchNo) {
   TraceParams p = c->params;
   p.batchFirst = first;
   p.batchCount = count;
-  {
-    // rays one wave pulls per queue access: enough grabs for balance, few enough
-    // to keep the queue word cold
-    const uint64_t waves = (uint64_t)c->grid * (VR_BLOCK / 64);
-    uint64_t chunk = 1024;
-    while (chunk > 64 && (uint64_t)count / chunk < waves * 8)
-      chunk >>= 1;
-    p.chunk = (uint32_t)chunk;
-  }
+  p.chunk = 32; // sort bins one wave pulls per queue access (~1024 rays)
   const bool tape = !c->absorb;
   const unsigned slot = c->overlap ? (unsigned)(batchNo & 1) : 0u;
   if (slot) {
-    p.rayA = c->dRayA2.p;
-    p.rayTape = tape ? c->dRayTape2.p : nullptr;
+    p.slotRec = c->dSlotRec2.p;
+    p.slotTape = tape ? c->dSlotTape2.p : nullptr;
+    p.binCount = c->dBinCount2.p;
   }
   p.workCounter = c->dCounters.p + 8 + slot;
   hipStream_t sg = c->overlap ? c->stream2 : c->stream;
@@ -844,14 +818,11 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
     c->evSort.push_back(e);
     c->evTraced.push_back(f);
   }
-  // generator / sorter
-  VR_HIP(c, hipMemsetAsync(c->dBinHist.p, 0, (size_t)c->numBins * 4, sg));
-  VR_HIP(c, hipMemsetAsync(c->dBinCursor.p, 0, (size_t)c->numBins * 4, sg));
-  VR_HIP(c, launch_gen(p, c->geo.D, tape, (unsigned)c->numCUs * 8u, sg));
-  VR_HIP(c, launch_scan(c->dBinHist.p, c->numBins, c->dScanTmp.p, sg));
-  if (c->overlap && batchNo >= 2) // the sorted buffer of this slot is free once batch b-2 is traced
+  // generator (writes the binned stream of this slot: free once batch b-2 is traced)
+  if (c->overlap && batchNo >= 2)
     VR_HIP(c, hipStreamWaitEvent(sg, c->evTraced[batchNo - 2], 0));
-  VR_HIP(c, launch_scatter(p, tape, sg));
+  VR_HIP(c, hipMemsetAsync(p.binCount, 0, ((size_t)c->numBins + 1) * 4, sg));
+  VR_HIP(c, launch_gen(p, c->geo.D, tape, (unsigned)c->numCUs * 8u, sg));
   // tracer
   if (c->overlap) {
     VR_HIP(c, hipEventRecord(c->evSort[batchNo], sg));
@@ -1153,12 +1124,12 @@ int vr_debug_source_sample(vr_context *c, const uint64_t *idx, uint32_t n, uint3
     if (r != VR_OK)
       return r;
   }
-  if (n > c->batchCap)
+  if (n > c->slotStride)
     return fail(c, VR_E_INVALID, "vr_debug_source_sample: more rays than one batch holds");
   TraceParams p = c->params;
   p.seed = seed;
   p.batchCount = n;
-  p.genBin = nullptr; // no binning
+  p.binCount = nullptr; // no binning: record i goes to slot i
   DevBuf<unsigned long long> dI;
   VR_HIP(c, dI.ensure(n));
   VR_HIP(c, hipMemcpy(dI.p, idx, (size_t)n * 8, hipMemcpyHostToDevice));
@@ -1167,7 +1138,7 @@ int vr_debug_source_sample(vr_context *c, const uint64_t *idx, uint32_t n, uint3
   VR_HIP(c, hipStreamSynchronize(c->stream));
   std::vector<float> A((size_t)n * 4), B((size_t)n * 4);
   A.resize((size_t)n * 8);
-  VR_HIP(c, hipMemcpy(A.data(), c->dGenA.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+  VR_HIP(c, hipMemcpy(A.data(), c->dSlotRec.p, (size_t)n * 32, hipMemcpyDeviceToHost));
   (void)B;
   for (uint32_t i = 0; i < n; ++i) {
     const float *r = &A[8 * (size_t)i];

@@ -8,7 +8,6 @@ namespace vr {
 
 hipError_t launch_gen(const TraceParams &p, int D, bool withTape, unsigned maxBlocks, hipStream_t s);
 hipError_t launch_scan(unsigned *data, unsigned n, unsigned *tmp, hipStream_t s);
-hipError_t launch_scatter(const TraceParams &p, bool withTape, hipStream_t s);
 hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, bool absorb, unsigned grid,
                         hipStream_t s);
 // resident 256-thread blocks per CU of the trace kernel instantiation (occupancy API)

@@ -111,22 +111,33 @@ template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p
   const float u2 = fold_unit((getc(org, p.secondDir) + getc(dir, p.secondDir) * t - p.lo2) * p.invExt2, p.bc1);
   int c2 = (int)(u2 * (float)p.binT2);
   c2 = c2 < 0 ? 0 : (c2 >= p.binT2 ? p.binT2 - 1 : c2);
-  return part1by1((unsigned)c1) | (part1by1((unsigned)c2) << 1);
+  // 8x8 tiles in row-major order, cells row-major inside a tile: consecutive bins are
+  // spatial neighbours without rounding the grid up to a power of two
+  const unsigned tile = (unsigned)(c2 >> 3) * (unsigned)p.binTiles + (unsigned)(c1 >> 3);
+  return tile * 64u + (((unsigned)c2 & 7u) << 3 | ((unsigned)c1 & 7u));
 }
 
 // ---------------------------------------------------------------------------
 // gen_kernel: ray index -> ray record
 // ---------------------------------------------------------------------------
+// Writes the ray record straight into its sort bin (no separate sort pass): the bin's
+// cursor hands out one of VR_BIN_CAP slots; a ray whose bin is full goes to the
+// overflow region, which is traced after the bins.  Returns the record slot.
 template <int D, int NPRE>
-__device__ __forceinline__ void gen_store(const TraceParams &p, unsigned i, const V3 &o, const V3 &d, unsigned k) {
-  float4 *rec = reinterpret_cast<float4 *>(p.genA) + 2 * (size_t)i; // 32-byte record {A, B}
+__device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, const V3 &o, const V3 &d, unsigned k) {
+  unsigned slot = i;
+  if (p.binCount) {
+    const unsigned b = bin_of<D>(p, o, project_dir<D>(d));
+    const unsigned pos = atomicAdd(&p.binCount[b], 1u);
+    if (pos < VR_BIN_CAP)
+      slot = b * VR_BIN_CAP + pos;
+    else
+      slot = p.numBins * VR_BIN_CAP + atomicAdd(&p.binCount[p.numBins], 1u); // < ovCap by construction
+  }
+  float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + 2 * (size_t)slot; // 32-byte record {A, B}
   rec[0] = make_float4(o.x, o.y, o.z, d.x);
   rec[1] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(k));
-  if (p.genBin) {
-    const unsigned b = bin_of<D>(p, o, project_dir<D>(d));
-    p.genBin[i] = b;
-    atomicAdd(&p.binHist[b], 1u);
-  }
+  return slot;
 }
 
 // Fixed number of source draws (no tilted primary direction): the K = draws +
@@ -143,11 +154,11 @@ __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
     int k = 0;
     V3 o, d;
     source_sample<D, HALF>(p, [&]() { return out[k++]; }, o, d); // k is a compile-time sequence after unrolling
-    gen_store<D, NPRE>(p, i, o, d, (unsigned)NS);
+    const unsigned slot = gen_store<D, NPRE>(p, i, o, d, (unsigned)NS);
     if (NPRE > 0) {
 #pragma unroll
       for (int s = 0; s < NPRE; ++s)
-        p.genTape[(size_t)s * p.batchCap + i] = out[NS + s];
+        p.slotTape[(size_t)s * p.slotStride + slot] = out[NS + s];
     }
   }
 }
@@ -166,11 +177,11 @@ template <int D, int NPRE> __global__ __launch_bounds__(VR_BLOCK) void gen_basis
     unsigned t2 = 0;
     V3 o, d;
     source_sample<D, false>(p, [&]() { return rng_next(rng, t2); }, o, d);
-    gen_store<D, NPRE>(p, i, o, d, rng.k);
+    const unsigned slot = gen_store<D, NPRE>(p, i, o, d, rng.k);
     if (NPRE > 0) {
 #pragma unroll
       for (int s = 0; s < NPRE; ++s)
-        p.genTape[(size_t)s * p.batchCap + i] = rng_next(rng, t2);
+        p.slotTape[(size_t)s * p.slotStride + slot] = rng_next(rng, t2);
     }
   }
 }
@@ -230,27 +241,6 @@ __global__ __launch_bounds__(VR_BLOCK) void scan_add_kernel(unsigned *data, unsi
   for (unsigned k = 0; k < SCAN_PER_THREAD; ++k)
     if (base + k < n)
       data[base + k] += off;
-}
-
-// ---------------------------------------------------------------------------
-// scatter_kernel: counting sort of the ray records by bin
-// ---------------------------------------------------------------------------
-template <int NPRE> __global__ __launch_bounds__(VR_BLOCK) void scatter_kernel(const TraceParams p) {
-  const unsigned i = blockIdx.x * VR_BLOCK + threadIdx.x;
-  if (i >= p.batchCount)
-    return;
-  const unsigned b = p.genBin[i];
-  const unsigned pos = p.binHist[b] + atomicAdd(&p.binCursor[b], 1u);
-  const float4 *src = reinterpret_cast<const float4 *>(p.genA) + 2 * (size_t)i;
-  float4 *dst = reinterpret_cast<float4 *>(p.rayA) + 2 * (size_t)pos;
-  const float4 ra = src[0], rb = src[1];
-  dst[0] = ra; // one 32-byte record: the two stores hit the same half cache line
-  dst[1] = rb;
-  if (NPRE > 0) {
-#pragma unroll
-    for (int s = 0; s < NPRE; ++s)
-      p.rayTape[(size_t)s * p.batchCap + pos] = p.genTape[(size_t)s * p.batchCap + i];
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -325,7 +315,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
   __syncthreads();
 
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
-  const float4 *__restrict__ rayAB = reinterpret_cast<const float4 *>(p.rayA);
+  const float4 *__restrict__ rayAB = reinterpret_cast<const float4 *>(p.slotRec);
   const float tnear = 1e-4f; // rayUtil.hpp:229-231
 
   // per-lane ray state
@@ -344,8 +334,14 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
   rng.seed = 0;
   // counters
   unsigned cTraces = 0, cNongeo = 0, cGeo = 0, cBoundary = 0, cRefl = 0, cTerm = 0, cTier2 = 0;
-  // wave-uniform work span
-  unsigned waveNext = 0, waveEnd = 0;
+  // wave-uniform cursor over the sort bins: [curBin, spanEnd) is the span of (virtual)
+  // bins this wave pulled from the queue; bins >= numBins are 64-ray chunks of the
+  // overflow region
+  typedef const unsigned __attribute__((address_space(4))) *ConstU32;
+  ConstU32 binCount = (ConstU32)p.binCount;
+  const unsigned ovCount = binCount[p.numBins] < p.ovCap ? binCount[p.numBins] : p.ovCap;
+  const unsigned totalBins = p.numBins + (ovCount + VR_BIN_CAP - 1) / VR_BIN_CAP;
+  unsigned curBin = 0, spanEnd = 0, curOff = 0, curCnt = 0, curBase = 0;
   bool exhausted = false;
 
   for (;;) {
@@ -353,28 +349,44 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
     // ~100 registers: occupancy matters more than 24 ds_reads per segment
     asm volatile("" ::: "memory");
     // ---- wave-wide compaction / restart: idle lanes pull the next sorted rays ----
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < 4;) {
       const unsigned long long idle = __ballot(!active);
       if (!idle)
         break;
-      if (waveNext == waveEnd) {
-        if (exhausted)
-          break;
-        unsigned long long s = 0;
-        if (lane == 0)
-          s = atomicAdd(p.workCounter, (unsigned long long)p.chunk);
-        s = bcast64(s);
-        if (s >= p.batchCount) {
-          exhausted = true;
-          break;
+      if (curOff >= curCnt) { // current bin used up: next bin of the span, or a new span
+        if (curBin + 1 >= spanEnd || spanEnd == 0) {
+          if (exhausted)
+            break;
+          unsigned long long s = 0;
+          if (lane == 0)
+            s = atomicAdd(p.workCounter, (unsigned long long)p.chunk);
+          s = bcast64(s);
+          if (s >= totalBins) {
+            exhausted = true;
+            break;
+          }
+          curBin = (unsigned)s;
+          spanEnd = (unsigned)((s + p.chunk < totalBins) ? s + p.chunk : totalBins);
+        } else {
+          ++curBin;
         }
-        waveNext = (unsigned)s;
-        waveEnd = (unsigned)((s + p.chunk < p.batchCount) ? s + p.chunk : p.batchCount);
+        curOff = 0;
+        if (curBin < p.numBins) {
+          const unsigned c = binCount[curBin];
+          curCnt = c < VR_BIN_CAP ? c : VR_BIN_CAP;
+          curBase = curBin * VR_BIN_CAP;
+        } else {
+          const unsigned k = (curBin - p.numBins) * VR_BIN_CAP;
+          curCnt = ovCount - k < VR_BIN_CAP ? ovCount - k : VR_BIN_CAP;
+          curBase = p.numBins * VR_BIN_CAP + k;
+        }
+        continue; // (an empty bin costs one scalar load)
       }
+      ++rep;
       const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
-      const unsigned avail = waveEnd - waveNext;
+      const unsigned avail = curCnt - curOff;
       if (!active && rank < avail) {
-        const unsigned j = waveNext + rank;
+        const unsigned j = curBase + curOff + rank;
         const float4 a = rayAB[2 * (size_t)j];
         const float4 b = rayAB[2 * (size_t)j + 1];
         org = mk(a.x, a.y, a.z);
@@ -393,11 +405,11 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
           rng.pos = 0xFFFFFFFFu;
 #pragma unroll
           for (int s = 0; s < NPRE; ++s)
-            tape[s * VR_BLOCK + tid] = p.rayTape[(size_t)s * p.batchCap + j];
+            tape[s * VR_BLOCK + tid] = p.slotTape[(size_t)s * p.slotStride + j];
         }
       }
       const unsigned nIdle = __popcll(idle);
-      waveNext += nIdle < avail ? nIdle : avail;
+      curOff += nIdle < avail ? nIdle : avail;
     }
     if (!__ballot(active))
       break;
@@ -602,17 +614,6 @@ hipError_t launch_scan(unsigned *data, unsigned n, unsigned *tmp /* >= 2 * ceil(
   if (e != hipSuccess)
     return e;
   hipLaunchKernelGGL(scan_add_kernel, dim3(blocks), dim3(VR_BLOCK), 0, s, data, n, tmp);
-  return hipGetLastError();
-}
-
-hipError_t launch_scatter(const TraceParams &p, bool withTape, hipStream_t s) {
-  const unsigned grid = (p.batchCount + VR_BLOCK - 1) / VR_BLOCK;
-  if (grid == 0)
-    return hipSuccess;
-  if (withTape)
-    hipLaunchKernelGGL((scatter_kernel<VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
-  else
-    hipLaunchKernelGGL((scatter_kernel<0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   return hipGetLastError();
 }
 

@@ -32,6 +32,7 @@ struct Tri {       // boundary wall triangle, Embree's precomputed form
 //   tape[s][i] (only for particles that keep going after a hit): raw engine
 //   outputs k .. k+VR_NPRE-1 of ray i, structure-of-arrays by slot
 constexpr int VR_NPRE = 8;
+constexpr unsigned VR_BIN_CAP = 64; // record slots per sort bin (one wavefront)
 
 // number of per-ray RNG outputs the generator keeps in its LDS tape (tier 1)
 constexpr int VR_TAPE = 16;
@@ -49,18 +50,17 @@ struct TraceParams {
   unsigned long long *counters;  // [8]
   unsigned long long *workCounter;
   unsigned long long *rngScratch; // [waves][312][64]
-  // ray stream of the current batch
-  float *genA, *genB;             // unsorted 32-byte records {A,B} in genA (genB unused)
-  unsigned long long *genTape;    // [VR_NPRE][batchCap] or nullptr
-  uint32_t *genBin;               // bin of each unsorted ray
-  float *rayA, *rayB;             // sorted 32-byte records in rayA (rayB unused)
-  unsigned long long *rayTape;
-  uint32_t *binHist;              // [numBins] counts -> exclusive starts
-  uint32_t *binCursor;            // [numBins]
+  // ray stream of the current batch: VR_BIN_CAP record slots per sort bin, then the
+  // overflow region (rays whose bin was full), all in one array of 32-byte records
+  float *slotRec;                 // [(numBins * VR_BIN_CAP + ovCap)] x 2 float4
+  unsigned long long *slotTape;   // [VR_NPRE][slotStride] or nullptr
+  uint32_t *binCount;             // [numBins + 1]; [numBins] counts the overflow rays
+                                  // (nullptr: diagnostics, record i goes to slot i)
   const unsigned long long *idxList; // diagnostics: explicit ray indices (or nullptr)
   uint64_t batchFirst;            // global ray index of the batch's ray 0
   uint32_t batchCount;            // rays in this batch
-  uint32_t batchCap;              // slot stride of the tapes
+  uint32_t slotStride;            // slots per tape plane (= total record slots)
+  uint32_t ovCap;                 // capacity of the overflow region
   uint32_t numBins;
   uint32_t seed;
   uint32_t numPrims;
@@ -79,6 +79,7 @@ struct TraceParams {
   float farCoord;                 // geometry bbox face opposite the source, on rayDir
   float invExt1, invExt2;         // 1 / (hi - lo) along firstDir / secondDir (0 if degenerate)
   int32_t binT1, binT2;           // cells per axis
+  int32_t binTiles;               // 8x8-cell tiles per row (3-D)
   uint32_t debugFlags;            // VR_DEBUG_FLAGS (timing experiments; 0 in production)
 };
 
