@@ -676,10 +676,14 @@ int vr_apply_prepare(vr_context *c) {
       c->overlap = false;
   // sort bins: far-plane cells holding ~32 rays each (half a wavefront), VR_BIN_CAP slots
   {
-    uint64_t target = std::max<uint64_t>(cap / 32, 1);
-    int T1, T2, tiles = 1;
+    uint32_t binCap = VR_BIN_CAP, perBin = 32;
+    if (const char *e = std::getenv("VR_BIN_CAP"))
+      binCap = (uint32_t)std::max(8, std::atoi(e));
     if (const char *e = std::getenv("VR_RAYS_PER_BIN"))
-      target = std::max<uint64_t>(cap / std::max(1, std::atoi(e)), 1);
+      perBin = (uint32_t)std::max(1, std::atoi(e));
+    p.binCap = binCap;
+    uint64_t target = std::max<uint64_t>(cap / perBin, 1);
+    int T1, T2, tiles = 1;
     uint32_t nb;
     if (D == 2) {
       T1 = (int)std::min<uint64_t>(target, 1u << 22);
@@ -694,7 +698,7 @@ int vr_apply_prepare(vr_context *c) {
     p.binT1 = T1;
     p.binT2 = T2;
     p.binTiles = tiles;
-    const size_t slots = (size_t)nb * VR_BIN_CAP + cap; // bins + overflow region
+    const size_t slots = (size_t)nb * binCap + cap; // bins + overflow region
     c->slotStride = slots;
     VR_HIP(c, c->dSlotRec.ensure(slots * 8));
     VR_HIP(c, c->dBinCount.ensure((size_t)nb + 1));

@@ -121,7 +121,7 @@ template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p
 // gen_kernel: ray index -> ray record
 // ---------------------------------------------------------------------------
 // Writes the ray record straight into its sort bin (no separate sort pass): the bin's
-// cursor hands out one of VR_BIN_CAP slots; a ray whose bin is full goes to the
+// cursor hands out one of p.binCap slots; a ray whose bin is full goes to the
 // overflow region, which is traced after the bins.  Returns the record slot.
 template <int D, int NPRE>
 __device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, const V3 &o, const V3 &d, unsigned k) {
@@ -129,10 +129,10 @@ __device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, 
   if (p.binCount) {
     const unsigned b = bin_of<D>(p, o, project_dir<D>(d));
     const unsigned pos = atomicAdd(&p.binCount[b], 1u);
-    if (pos < VR_BIN_CAP)
-      slot = b * VR_BIN_CAP + pos;
+    if (pos < p.binCap)
+      slot = b * p.binCap + pos;
     else
-      slot = p.numBins * VR_BIN_CAP + atomicAdd(&p.binCount[p.numBins], 1u); // < ovCap by construction
+      slot = p.numBins * p.binCap + atomicAdd(&p.binCount[p.numBins], 1u); // < ovCap by construction
   }
   float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + 2 * (size_t)slot; // 32-byte record {A, B}
   rec[0] = make_float4(o.x, o.y, o.z, d.x);
@@ -340,8 +340,9 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
   typedef const unsigned __attribute__((address_space(4))) *ConstU32;
   ConstU32 binCount = (ConstU32)p.binCount;
   const unsigned ovCount = binCount[p.numBins] < p.ovCap ? binCount[p.numBins] : p.ovCap;
-  const unsigned totalBins = p.numBins + (ovCount + VR_BIN_CAP - 1) / VR_BIN_CAP;
-  unsigned curBin = 0, spanEnd = 0, curOff = 0, curCnt = 0, curBase = 0;
+  const unsigned totalBins = p.numBins + (ovCount + p.binCap - 1) / p.binCap;
+  unsigned curBin = 0, spanStart = 0, spanEnd = 0, curOff = 0, curCnt = 0, curBase = 0;
+  unsigned spanCounts = 0; // lane i: ray count of bin spanStart + i
   bool exhausted = false;
 
   for (;;) {
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
     // ~100 registers: occupancy matters more than 24 ds_reads per segment
     asm volatile("" ::: "memory");
     // ---- wave-wide compaction / restart: idle lanes pull the next sorted rays ----
-    for (int rep = 0; rep < 4;) {
+    for (int rep = 0; rep < 8;) {
       const unsigned long long idle = __ballot(!active);
       if (!idle)
         break;
@@ -365,22 +366,26 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
             exhausted = true;
             break;
           }
-          curBin = (unsigned)s;
+          curBin = spanStart = (unsigned)s;
           spanEnd = (unsigned)((s + p.chunk < totalBins) ? s + p.chunk : totalBins);
+          // the span's bin counts in one coalesced load (lane i <- bin spanStart + i; chunk <= 64)
+          const unsigned bi = spanStart + lane;
+          spanCounts = (bi < spanEnd && bi < p.numBins) ? p.binCount[bi] : 0u;
         } else {
           ++curBin;
         }
         curOff = 0;
         if (curBin < p.numBins) {
-          const unsigned c = binCount[curBin];
-          curCnt = c < VR_BIN_CAP ? c : VR_BIN_CAP;
-          curBase = curBin * VR_BIN_CAP;
+          const unsigned c = __shfl(spanCounts, (int)(curBin - spanStart), 64);
+          curCnt = c < p.binCap ? c : p.binCap;
+          curBase = curBin * p.binCap;
         } else {
-          const unsigned k = (curBin - p.numBins) * VR_BIN_CAP;
-          curCnt = ovCount - k < VR_BIN_CAP ? ovCount - k : VR_BIN_CAP;
-          curBase = p.numBins * VR_BIN_CAP + k;
+          const unsigned k = (curBin - p.numBins) * p.binCap;
+          curCnt = ovCount - k < p.binCap ? ovCount - k : p.binCap;
+          curBase = p.numBins * p.binCap + k;
         }
-        continue; // (an empty bin costs one scalar load)
+        curCnt = __builtin_amdgcn_readfirstlane(curCnt);
+        continue;
       }
       ++rep;
       const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));

@@ -61,6 +61,7 @@ struct TraceParams {
   uint32_t batchCount;            // rays in this batch
   uint32_t slotStride;            // slots per tape plane (= total record slots)
   uint32_t ovCap;                 // capacity of the overflow region
+  uint32_t binCap;                // record slots per sort bin
   uint32_t numBins;
   uint32_t seed;
   uint32_t numPrims;
