@@ -670,10 +670,12 @@ int vr_apply_prepare(vr_context *c) {
     cap = (uint32_t)std::min<uint64_t>(span, std::max<long long>(256, std::atoll(e)));
   cap = std::max<uint32_t>(cap, 1u);
   c->batchCap = cap;
-  c->overlap = span > cap;
-  if (const char *e = std::getenv("VR_NO_OVERLAP"))
-    if (std::atoi(e))
-      c->overlap = false;
+  // Overlapping the generator of batch b+1 (second stream) with the tracer of batch b was
+  // measured SLOWER on MI355X (both kernels contend for the same CUs and smaller batches
+  // sort less coherently): 16.7 ms vs 14.7 ms per 1e8 rays.  Kept behind VR_OVERLAP=1.
+  c->overlap = false;
+  if (const char *e = std::getenv("VR_OVERLAP"))
+    c->overlap = std::atoi(e) != 0 && span > cap;
   // sort bins: far-plane cells holding ~32 rays each (half a wavefront), VR_BIN_CAP slots
   {
     uint32_t binCap = VR_BIN_CAP, perBin = 32;

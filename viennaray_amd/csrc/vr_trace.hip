@@ -126,7 +126,7 @@ template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p
 template <int D, int NPRE>
 __device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, const V3 &o, const V3 &d, unsigned k) {
   unsigned slot = i;
-  if (p.binCount) {
+  if (p.binCount && !(p.debugFlags & 64u)) { // flag 64: timing experiment, no binning
     const unsigned b = bin_of<D>(p, o, project_dir<D>(d));
     const unsigned pos = atomicAdd(&p.binCount[b], 1u);
     if (pos < p.binCap)
