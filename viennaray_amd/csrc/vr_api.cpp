@@ -702,15 +702,12 @@ int vr_apply_prepare(vr_context *c) {
     p.binTiles = tiles;
     const size_t slots = (size_t)nb * binCap + cap; // bins + overflow region
     c->slotStride = slots;
-    VR_HIP(c, c->dSlotRec.ensure(slots * 8));
+    const size_t recFloats = c->absorb ? 8 : 8 + 2 * VR_NPRE; // 32 B, or 32 B + 8 raw outputs
+    VR_HIP(c, c->dSlotRec.ensure(slots * recFloats));
     VR_HIP(c, c->dBinCount.ensure((size_t)nb + 1));
-    if (!c->absorb)
-      VR_HIP(c, c->dSlotTape.ensure(slots * VR_NPRE));
     if (c->overlap) {
-      VR_HIP(c, c->dSlotRec2.ensure(slots * 8));
+      VR_HIP(c, c->dSlotRec2.ensure(slots * recFloats));
       VR_HIP(c, c->dBinCount2.ensure((size_t)nb + 1));
-      if (!c->absorb)
-        VR_HIP(c, c->dSlotTape2.ensure(slots * VR_NPRE));
     }
   }
 

@@ -134,7 +134,8 @@ __device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, 
     else
       slot = p.numBins * p.binCap + atomicAdd(&p.binCount[p.numBins], 1u); // < ovCap by construction
   }
-  float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + 2 * (size_t)slot; // 32-byte record {A, B}
+  // record = {A, B} (32 B) [+ VR_NPRE raw engine outputs (64 B) when the particle keeps going]
+  float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + (size_t)(NPRE > 0 ? 2 + NPRE / 2 : 2) * slot;
   rec[0] = make_float4(o.x, o.y, o.z, d.x);
   rec[1] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(k));
   return slot;
@@ -156,9 +157,11 @@ __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
     source_sample<D, HALF>(p, [&]() { return out[k++]; }, o, d); // k is a compile-time sequence after unrolling
     const unsigned slot = gen_store<D, NPRE>(p, i, o, d, (unsigned)NS);
     if (NPRE > 0) {
+      ulonglong2 *tp = reinterpret_cast<ulonglong2 *>(reinterpret_cast<float4 *>(p.slotRec) +
+                                                        (size_t)(2 + NPRE / 2) * slot + 2);
 #pragma unroll
-      for (int s = 0; s < NPRE; ++s)
-        p.slotTape[(size_t)s * p.slotStride + slot] = out[NS + s];
+      for (int s = 0; s < NPRE / 2; ++s)
+        tp[s] = make_ulonglong2(out[NS + 2 * s], out[NS + 2 * s + 1]);
     }
   }
 }
@@ -179,9 +182,14 @@ template <int D, int NPRE> __global__ __launch_bounds__(VR_BLOCK) void gen_basis
     source_sample<D, false>(p, [&]() { return rng_next(rng, t2); }, o, d);
     const unsigned slot = gen_store<D, NPRE>(p, i, o, d, rng.k);
     if (NPRE > 0) {
+      ulonglong2 *tp = reinterpret_cast<ulonglong2 *>(reinterpret_cast<float4 *>(p.slotRec) +
+                                                        (size_t)(2 + NPRE / 2) * slot + 2);
 #pragma unroll
-      for (int s = 0; s < NPRE; ++s)
-        p.slotTape[(size_t)s * p.slotStride + slot] = rng_next(rng, t2);
+      for (int s = 0; s < NPRE / 2; ++s) {
+        const u64 a = rng_next(rng, t2);
+        const u64 b = rng_next(rng, t2);
+        tp[s] = make_ulonglong2(a, b);
+      }
     }
   }
 }
@@ -392,8 +400,9 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
       const unsigned avail = curCnt - curOff;
       if (!active && rank < avail) {
         const unsigned j = curBase + curOff + rank;
-        const float4 a = rayAB[2 * (size_t)j];
-        const float4 b = rayAB[2 * (size_t)j + 1];
+        constexpr unsigned REC = NPRE > 0 ? 2 + NPRE / 2 : 2; // float4 per record
+        const float4 a = rayAB[REC * (size_t)j];
+        const float4 b = rayAB[REC * (size_t)j + 1];
         org = mk(a.x, a.y, a.z);
         rayDirection = mk(a.w, b.x, b.y);
         dir = project_dir<D>(rayDirection); // what Embree sees (rayUtil.hpp:204-227)
@@ -408,9 +417,13 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
           rng.seed = tea3((unsigned)(p.batchFirst + idxOff), p.seed);
           rng.k = rng.k0 = __float_as_uint(b.w);
           rng.pos = 0xFFFFFFFFu;
+          const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(rayAB + REC * (size_t)j + 2);
 #pragma unroll
-          for (int s = 0; s < NPRE; ++s)
-            tape[s * VR_BLOCK + tid] = p.slotTape[(size_t)s * p.slotStride + j];
+          for (int s = 0; s < NPRE / 2; ++s) {
+            const ulonglong2 v = tp[s];
+            tape[(2 * s) * VR_BLOCK + tid] = v.x;
+            tape[(2 * s + 1) * VR_BLOCK + tid] = v.y;
+          }
         }
       }
       const unsigned nIdle = __popcll(idle);

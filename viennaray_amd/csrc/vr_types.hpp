@@ -52,8 +52,8 @@ struct TraceParams {
   unsigned long long *rngScratch; // [waves][312][64]
   // ray stream of the current batch: VR_BIN_CAP record slots per sort bin, then the
   // overflow region (rays whose bin was full), all in one array of 32-byte records
-  float *slotRec;                 // [(numBins * VR_BIN_CAP + ovCap)] x 2 float4
-  unsigned long long *slotTape;   // [VR_NPRE][slotStride] or nullptr
+  float *slotRec;                 // [(numBins * binCap + ovCap)] records of 32 B (+ 64 B tape)
+  unsigned long long *slotTape;   // unused (the tape lives in the record)
   uint32_t *binCount;             // [numBins + 1]; [numBins] counts the overflow rays
                                   // (nullptr: diagnostics, record i goes to slot i)
   const unsigned long long *idxList; // diagnostics: explicit ray indices (or nullptr)
