@@ -82,7 +82,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
     if not vr.device_available():
         raise SystemExit("bench.py: no HIP device; the flux tracer has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -158,7 +158,7 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 if tj.get("grid") == n and tj.get("rays") == args.rays and tj.get("sticking") == args.sticking:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic = tj.get("hbm_bytes_per_launch")  # (2*FETCH_SIZE + WRITE_SIZE) * 1024, trace_kernel
             except Exception:
                 traffic = None
         out = {

@@ -23,3 +23,22 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.cs
     print("== pmc:", os.path.relpath(f, d))
     for (disp, k), cs in sorted(agg.items(), key=lambda x: int(x[0][0])):
         print("  dispatch", disp, k, {c: v for c, v in cs.items()})
+
+# traffic of the dominant kernel per launch (MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 64-B
+# requests of 128-B wide reads as 64 B -> doubled; WRITE_SIZE exact), KB -> bytes
+import json
+vals = {}
+for name in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(d, "pmc_%s" % name, "**", "*counter_collection.csv"), recursive=True):
+        per = defaultdict(float)
+        for r in csv.DictReader(open(f)):
+            if "trace_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == name:
+                per[r.get("Dispatch_Id")] += float(r.get("Counter_Value", 0))
+        if per:
+            vals[name] = sum(per.values()) / len(per)
+if len(vals) == 2:
+    out = {"kernel": "trace_kernel", "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
+           "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
+           "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per trace_kernel launch; fabric requests incl. Infinity-Cache hits"}
+    print("== traffic:", json.dumps(out))
+    json.dump(out, open(os.path.join(d, "traffic.json"), "w"))

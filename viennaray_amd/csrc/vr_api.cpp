@@ -781,6 +781,9 @@ int vr_apply_prepare(vr_context *c) {
   p.farCoord = c->ts[3] ? c->geo.minC[c->ts[0]] : c->geo.maxC[c->ts[0]];
   p.invExt1 = (p.hi1 > p.lo1) ? 1.f / (p.hi1 - p.lo1) : 0.f;
   p.invExt2 = (p.hi2 > p.lo2) ? 1.f / (p.hi2 - p.lo2) : 0.f;
+  p.packetBudget = 128;
+  if (const char *e = std::getenv("VR_PACKET_BUDGET"))
+    p.packetBudget = (uint32_t)std::max(0, std::atoi(e));
   p.debugFlags = 0;
   if (const char *e = std::getenv("VR_DEBUG_FLAGS"))
     p.debugFlags = (uint32_t)std::atoi(e);

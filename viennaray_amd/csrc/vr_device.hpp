@@ -386,17 +386,23 @@ __device__ __forceinline__ void bvh_hit_lane(const TraceParams &p, const V3 &o, 
 typedef float vf4 __attribute__((ext_vector_type(4)));
 typedef const vf4 __attribute__((address_space(4))) *ConstF4;
 
+// `budget` bounds the number of node visits: a packet whose rays turn out to be
+// incoherent (union of paths much larger than one path) gives up and returns false;
+// the hits found so far are real hits and stay in `h`, the caller finishes with the
+// per-lane traversal.
 template <int GEO>
-__device__ __forceinline__ void bvh_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
-                                               HitRec &h) {
+__device__ __forceinline__ bool bvh_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
+                                               HitRec &h, unsigned budget) {
   if (p.numPrims == 0)
-    return;
+    return true;
   ConstF4 nodes = (ConstF4)(p.nodes);
   ConstF4 prims = (ConstF4)(p.prims);
   const V3 inv = safe_inverse(d);
   const V3 oi = V3{o.x * inv.x, o.y * inv.y, o.z * inv.z};
   unsigned node = 0; // wave-uniform
   while (node != VR_END) {
+    if (budget-- == 0u)
+      return false;
     const vf4 q0 = nodes[2 * node];
     const vf4 q1 = nodes[2 * node + 1];
     const float tx0 = __builtin_fmaf(q0.x, inv.x, -oi.x), tx1 = __builtin_fmaf(q1.x, inv.x, -oi.x);
@@ -433,6 +439,7 @@ __device__ __forceinline__ void bvh_hit_packet(const TraceParams &p, bool part, 
       node = esc;
     }
   }
+  return true;
 }
 
 template <int GEO>

@@ -438,13 +438,17 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
     // have scattered: per-lane traversal.
     HitRec h;
     hit_init_walls(p, wallS, org, dir, tnear, h); // (idle lanes compute on stale values; unused)
-    const bool packetLane = active && fresh;
-    const bool usePacket = !(p.debugFlags & 32u) && __popcll(__ballot(packetLane)) >= 8;
+    // Every iteration first tries the wave-uniform packet traversal for all active lanes
+    // with a bounded number of node visits: freshly sorted rays, and rays that left the
+    // same surface patch, finish well inside the budget; a scattered set of rays
+    // exhausts it and is finished lane by lane.
+    const bool usePacket = !(p.debugFlags & 32u) && __popcll(__ballot(active)) >= 8;
+    bool packetDone = false;
     if (usePacket)
-      bvh_hit_packet<GEO>(p, packetLane, org, dir, tnear, h);
-    if (active && !(usePacket && fresh))
+      packetDone = bvh_hit_packet<GEO>(p, active, org, dir, tnear, h, p.packetBudget);
+    if (active && !packetDone)
       bvh_hit_lane<GEO>(p, org, dir, tnear, h);
-    fresh = false;
+    (void)fresh;
 
     if (active) {
       // ---- the reference's state machine for this segment (rayTraceKernel.hpp:169-335) ----

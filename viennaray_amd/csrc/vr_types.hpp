@@ -81,6 +81,7 @@ struct TraceParams {
   float invExt1, invExt2;         // 1 / (hi - lo) along firstDir / secondDir (0 if degenerate)
   int32_t binT1, binT2;           // cells per axis
   int32_t binTiles;               // 8x8-cell tiles per row (3-D)
+  uint32_t packetBudget;          // node visits a packet traversal may spend before giving up
   uint32_t debugFlags;            // VR_DEBUG_FLAGS (timing experiments; 0 in production)
 };
 
