@@ -1,0 +1,48 @@
+// libm_check — exhaustive comparison of vr_libm.hpp (host build) with the running glibc.
+// usage: libm_check [quick]   prints mismatch counts; exit code 1 on any mismatch.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <omp.h>
+
+#include "../../viennaray_amd/csrc/vr_libm.hpp"
+
+int main(int argc, char **argv) {
+  const bool quick = argc > 1;
+  const uint32_t step = quick ? 97u : 1u;
+  // sincosf on every float in [0, 2*pi] (the source's phi = (float)(2*pi*r1))
+  const uint32_t hi = vr::vr_asuint(6.2831855f);
+  long badS = 0, badC = 0, n = 0;
+#pragma omp parallel for reduction(+ : badS, badC, n) schedule(static)
+  for (long u = 0; u <= (long)hi; u += step) {
+    const float x = vr::vr_asfloat((uint32_t)u);
+    float s0, c0, s1, c1;
+    sincosf(x, &s0, &c0);
+    vr::glibc_sincosf(x, s1, c1);
+    badS += std::memcmp(&s0, &s1, 4) != 0;
+    badC += std::memcmp(&c0, &c1, 4) != 0;
+    ++n;
+  }
+  std::printf("sincosf: %ld inputs, sin mismatches %ld, cos mismatches %ld\n", n, badS, badC);
+  // powf(x, ee) on every float x in [0, 1] for the exponents ee = 1/(power+1)
+  const float powers[] = {1.f, 2.f, 5.f, 20.f, 50.f, 100.f, 1000.f, 0.5f};
+  long badP = 0;
+  for (float pw : powers) {
+    const float ee = 1.f / (pw + 1.f);
+    long bad = 0, m = 0;
+    const uint32_t one = vr::vr_asuint(1.0f);
+#pragma omp parallel for reduction(+ : bad, m) schedule(static)
+    for (long u = 0; u <= (long)one; u += step) {
+      const float x = vr::vr_asfloat((uint32_t)u);
+      if (u != 0 && u < 0x00800000)
+        continue; // subnormals cannot come out of generate_canonical
+      const float a = powf(x, ee), b = vr::glibc_powf(x, ee);
+      bad += std::memcmp(&a, &b, 4) != 0;
+      ++m;
+    }
+    std::printf("powf(x, %.9g): %ld inputs, mismatches %ld\n", ee, m, bad);
+    badP += bad;
+  }
+  return (badS || badC || badP) ? 1 : 0;
+}

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "vr_libm.hpp"
 #include "vr_types.hpp"
 
 namespace vr {
@@ -487,48 +488,14 @@ template <int D> __device__ __forceinline__ V3 project_dir(V3 d) {
   return d;
 }
 
-// sin/cos of x in [0, 2*pi] in double: quadrant reduction with a two-part pi/2
-// and the classic degree-13/14 minimax kernels on [-pi/4, pi/4] (error < 1 ulp of
-// double, i.e. ~1e-9 ulp of the float the result is rounded to).
-__device__ __forceinline__ void sincos_0_2pi(double x, double &s, double &c) {
-  const double n = rint(x * 6.36619772367581382433e-01); // 2/pi
-  double r = x - n * 1.57079632673412561417e+00;         // pi/2, high 33 bits
-  r = r - n * 6.07710050650619224932e-11;                // pi/2, tail
-  const double z = r * r;
-  const double ps = -1.66666666666666324348e-01 +
-                    z * (8.33333333332248946124e-03 +
-                         z * (-1.98412698298579493134e-04 +
-                              z * (2.75573137070700676789e-06 +
-                                   z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
-  const double pc = 4.16666666666666019037e-02 +
-                    z * (-1.38888888888741095749e-03 +
-                         z * (2.48015872894767294178e-05 +
-                              z * (-2.75573143513906633035e-07 +
-                                   z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
-  const double sr = r + r * z * ps;
-  const double cr = 1.0 - 0.5 * z + z * z * pc;
-  const int q = (int)n & 3;
-  const double ss = (q & 1) ? cr : sr;
-  const double cc = (q & 1) ? sr : cr;
-  s = (q & 2) ? -ss : ss;
-  c = ((q + 1) & 2) ? -cc : cc;
-}
-
-// raySourceRandom.hpp:70-116: one power-cosine sample in the local frame.
-// glibc's sincosf/powf are stood in for by double-precision evaluation rounded
-// to float (differs from glibc in ~1 % of samples by 1 ulp).
-template <bool HALF>
+// raySourceRandom.hpp:70-116: one power-cosine sample in the local frame, with glibc's
+// float sincosf / powf reproduced bit for bit (vr_libm.hpp), so the device traces the
+// very rays the reference's CPU loop traces.
 __device__ __forceinline__ void cosine_sample(float r1, float r2, float ee, float &cosTheta, float &sinTheta,
                                               float &cosPhi, float &sinPhi) {
-  const float ang = (float)(3.14159265358979323846 * 2. * (double)r1);
-  double s, c;
-  sincos_0_2pi((double)ang, s, c);
-  sinPhi = (float)s;
-  cosPhi = (float)c;
-  if (HALF) // cosine source (power 1, ee == 1/2): pow(x, 1/2) correctly rounded = sqrt
-    cosTheta = (float)sqrt((double)r2);
-  else
-    cosTheta = (float)pow((double)r2, (double)ee);
+  const float ang = (float)(3.14159265358979323846 * 2. * (double)r1); // rayUtil.hpp:247-256
+  glibc_sincosf(ang, sinPhi, cosPhi);
+  cosTheta = glibc_powf(r2, ee);                                      // std::pow(float, float)
   sinTheta = (float)sqrt(1. - (double)(cosTheta * cosTheta));
 }
 

@@ -34,7 +34,7 @@ __device__ __forceinline__ u64 weight_fx(float w) { return (u64)((double)w * 109
 // source sampling (raySourceRandom.hpp:25-116)
 // ---------------------------------------------------------------------------
 // `draw()` returns the next raw 64-bit engine output
-template <int D, bool HALF, class Draw>
+template <int D, class Draw>
 __device__ __forceinline__ void source_sample(const TraceParams &p, Draw &&draw, V3 &org, V3 &dir) {
   // origin draws first (raySourceRandom.hpp:50-68)
   org = mk(0.f, 0.f, 0.f);
@@ -52,7 +52,7 @@ __device__ __forceinline__ void source_sample(const TraceParams &p, Draw &&draw,
     const float d1 = canon_f32(draw());
     const float d2 = canon_f32(draw());
     float ct, st, cp, sp;
-    cosine_sample<HALF>(d1, d2, p.ee, ct, st, cp, sp);
+    cosine_sample(d1, d2, p.ee, ct, st, cp, sp);
     dir = mk(0.f, 0.f, 0.f);
     setc(dir, p.rayDir, p.posNeg * ct);
     setc(dir, p.firstDir, cp * st);
@@ -63,7 +63,7 @@ __device__ __forceinline__ void source_sample(const TraceParams &p, Draw &&draw,
       const float d1 = canon_f32(draw());
       const float d2 = canon_f32(draw());
       float ct, st, cp, sp;
-      cosine_sample<HALF>(d1, d2, p.ee, ct, st, cp, sp);
+      cosine_sample(d1, d2, p.ee, ct, st, cp, sp);
       const float a = ct, b = cp * st, c = sp * st;
       dir.x = (p.basis[0] * a + p.basis[3] * b) + p.basis[6] * c;
       dir.y = (p.basis[1] * a + p.basis[4] * b) + p.basis[7] * c;
@@ -144,8 +144,7 @@ __device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, 
 // Fixed number of source draws (no tilted primary direction): the K = draws +
 // NPRE engine outputs a ray needs are produced straight into registers — no LDS
 // tape, no tier 2 — by one 156+K-step pass of the seeding recurrence.
-template <int D, int NPRE, bool HALF>
-__global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
+template <int D, int NPRE> __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
   constexpr int NS = D == 3 ? 4 : 3;
   constexpr int K = NS + NPRE;
   for (unsigned i = blockIdx.x * VR_BLOCK + threadIdx.x; i < p.batchCount; i += gridDim.x * VR_BLOCK) {
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
     mt_first_outputs<K>(tea3((unsigned)idx, p.seed), out);
     int k = 0;
     V3 o, d;
-    source_sample<D, HALF>(p, [&]() { return out[k++]; }, o, d); // k is a compile-time sequence after unrolling
+    source_sample<D>(p, [&]() { return out[k++]; }, o, d); // k is a compile-time sequence after unrolling
     const unsigned slot = gen_store<D, NPRE>(p, i, o, d, (unsigned)NS);
     if (NPRE > 0) {
       ulonglong2 *tp = reinterpret_cast<ulonglong2 *>(reinterpret_cast<float4 *>(p.slotRec) +
@@ -179,7 +178,7 @@ template <int D, int NPRE> __global__ __launch_bounds__(VR_BLOCK) void gen_basis
     rng_init(rng, tea3((unsigned)idx, p.seed), tape + tid, scratchLane);
     unsigned t2 = 0;
     V3 o, d;
-    source_sample<D, false>(p, [&]() { return rng_next(rng, t2); }, o, d);
+    source_sample<D>(p, [&]() { return rng_next(rng, t2); }, o, d);
     const unsigned slot = gen_store<D, NPRE>(p, i, o, d, rng.k);
     if (NPRE > 0) {
       ulonglong2 *tp = reinterpret_cast<ulonglong2 *>(reinterpret_cast<float4 *>(p.slotRec) +
@@ -606,20 +605,15 @@ hipError_t launch_gen(const TraceParams &p, int D, bool withTape, unsigned maxBl
     return hipSuccess;
   if (grid > maxBlocks)
     grid = maxBlocks; // grid-stride; bounds the tier-2 slabs to grid waves
-  const bool half = p.ee == 0.5f;
-  const int key = (p.useBasis ? 8 : (half ? 4 : 0)) | (D == 2 ? 0 : 2) | (withTape ? 1 : 0);
+  const int key = (p.useBasis ? 4 : 0) | (D == 2 ? 0 : 2) | (withTape ? 1 : 0);
   switch (key) {
-  case 0: hipLaunchKernelGGL((gen_kernel<2, 0, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 1: hipLaunchKernelGGL((gen_kernel<2, VR_NPRE, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 2: hipLaunchKernelGGL((gen_kernel<3, 0, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 3: hipLaunchKernelGGL((gen_kernel<3, VR_NPRE, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 4: hipLaunchKernelGGL((gen_kernel<2, 0, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 5: hipLaunchKernelGGL((gen_kernel<2, VR_NPRE, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 6: hipLaunchKernelGGL((gen_kernel<3, 0, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 7: hipLaunchKernelGGL((gen_kernel<3, VR_NPRE, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 8: hipLaunchKernelGGL((gen_basis_kernel<2, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 9: hipLaunchKernelGGL((gen_basis_kernel<2, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 10: hipLaunchKernelGGL((gen_basis_kernel<3, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 0: hipLaunchKernelGGL((gen_kernel<2, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 1: hipLaunchKernelGGL((gen_kernel<2, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 2: hipLaunchKernelGGL((gen_kernel<3, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 3: hipLaunchKernelGGL((gen_kernel<3, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 4: hipLaunchKernelGGL((gen_basis_kernel<2, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 5: hipLaunchKernelGGL((gen_basis_kernel<2, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 6: hipLaunchKernelGGL((gen_basis_kernel<3, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
   default: hipLaunchKernelGGL((gen_basis_kernel<3, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
   }
   return hipGetLastError();
