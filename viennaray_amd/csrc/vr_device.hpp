@@ -167,9 +167,43 @@ __device__ __noinline__ void rng_tier2_twist(Rng &r) {
   s[311 * 64] = mt_twist(cur, s[0], s[155 * 64]);
 }
 
-__device__ __forceinline__ u64 rng_next(Rng &r, unsigned &tier2Count) {
+// Tier 1b: refill the LDS tape with outputs [k0, k0 + W) of the engine, for k0 + W <= 156,
+// by re-walking the seeding recurrence (k0 + 155 + W steps) and keeping only the
+// 2W + 1 state words those outputs depend on: s[k0 .. k0+W] and s[k0+156 .. k0+155+W].
+// No global memory, ~1/3 of the work of building and twisting the full 312-word state.
+// The tape must have 2W + 1 slots: W outputs land in slots 0..W-1.
+template <int W> __device__ __noinline__ void rng_window(Rng &r, unsigned k0) {
+  u64 *t = r.tape;
+  u64 x = r.seed;
+  if (k0 == 0)
+    t[0] = x;
+  const unsigned last = k0 + 155u + (unsigned)W;
+  for (unsigned j = 1; j <= last; ++j) {
+    x = mt_step(x, j);
+    if (j >= k0 && j <= k0 + (unsigned)W)
+      t[(j - k0) * VR_BLOCK] = x;                       // low words, slots 0..W
+    else if (j >= k0 + 156u)
+      t[((unsigned)W + 1u + (j - k0 - 156u)) * VR_BLOCK] = x; // high words, slots W+1..2W
+  }
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
+    const u64 a = t[i * VR_BLOCK], b = t[(i + 1) * VR_BLOCK], c = t[(W + 1 + i) * VR_BLOCK];
+    t[i * VR_BLOCK] = mt_temper(mt_twist(a, b, c));
+  }
+  r.k0 = k0;
+  r.nTape = W;
+}
+
+// WINDOW > 0: the tape has 2*WINDOW+1 slots and may be refilled by rng_window
+template <int WINDOW = 0> __device__ __forceinline__ u64 rng_next(Rng &r, unsigned &tier2Count) {
   if (r.k - r.k0 < r.nTape) {
     u64 v = r.tape[(r.k - r.k0) * VR_BLOCK];
+    ++r.k;
+    return v;
+  }
+  if (WINDOW > 0 && r.pos == 0xFFFFFFFFu && r.k + (unsigned)WINDOW <= 156u) {
+    rng_window<(WINDOW > 0 ? WINDOW : 1)>(r, r.k);
+    u64 v = r.tape[0];
     ++r.k;
     return v;
   }

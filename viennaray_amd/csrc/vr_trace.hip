@@ -257,8 +257,8 @@ template <int D> __device__ __forceinline__ V3 reflect_diffuse(const V3 &n, Rng 
   float x, y;
   double x2py2;
   do {
-    x = canon_f32(rng_next(rng, t2)) * 2.0f + -1.0f;
-    y = canon_f32(rng_next(rng, t2)) * 2.0f + -1.0f;
+    x = canon_f32(rng_next<VR_NPRE>(rng, t2)) * 2.0f + -1.0f;
+    y = canon_f32(rng_next<VR_NPRE>(rng, t2)) * 2.0f + -1.0f;
     x2py2 = (double)(x * x + y * y);
   } while (x2py2 >= 1.);
   const double tmp = 2. * sqrt(1. - x2py2);
@@ -313,7 +313,7 @@ template <int D, int GEO, int PARTICLE, bool ABSORB>
 __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
   constexpr int NPRE = ABSORB ? 0 : VR_NPRE;
   __shared__ float wallS[96];
-  __shared__ u64 tape[NPRE > 0 ? NPRE * VR_BLOCK : 1];
+  __shared__ u64 tape[NPRE > 0 ? (2 * NPRE + 1) * VR_BLOCK : 1]; // 2W+1 slots: see rng_window
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
@@ -415,6 +415,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
           const unsigned idxOff = __float_as_uint(b.z);
           rng.seed = tea3((unsigned)(p.batchFirst + idxOff), p.seed);
           rng.k = rng.k0 = __float_as_uint(b.w);
+          rng.nTape = NPRE;
           rng.pos = 0xFFFFFFFFu;
           const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(rayAB + REC * (size_t)j + 2);
 #pragma unroll
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
                   bool reflect = true;
                   if (!(rayWeight >= lowerThreshold)) {
                     const double killProbability = 1.0 - (double)(rayWeight / renewWeight);
-                    if (canon_f64(rng_next(rng, cTier2)) < killProbability)
+                    if (canon_f64(rng_next<VR_NPRE>(rng, cTier2)) < killProbability)
                       reflect = false;
                     else
                       rayWeight = renewWeight;
