@@ -105,7 +105,9 @@ struct vr_context {
   DevBuf<float> dSlotRec, dSlotRec2, dWalls;
   DevBuf<unsigned long long> dSlotTape, dSlotTape2;
   DevBuf<uint32_t> dBinCount, dBinCount2;
+  DevBuf<float> dProbe; // {sum, count} of first-hit coordinates of the probe batch
   size_t slotStride = 0;
+  uint32_t raysPerBin = 32;
   std::vector<hipEvent_t> evSort, evTraced; // per batch: sorted stream ready / trace finished
   bool overlap = false;
   DevBuf<uint32_t> dScanTmp;
@@ -136,6 +138,8 @@ static int fail(vr_context *c, int code, const char *msg) {
     c->err = msg;
   return code;
 }
+
+static void size_bins(int D, uint64_t count, uint32_t perBin, TraceParams &p, uint32_t &numBins);
 
 extern "C" {
 
@@ -198,6 +202,7 @@ void vr_destroy(vr_context *c) {
   c->dSlotTape2.release();
   c->dBinCount.release();
   c->dBinCount2.release();
+  c->dProbe.release();
   c->dScanTmp.release();
   for (auto e : c->evK)
     (void)hipEventDestroy(e);
@@ -684,27 +689,16 @@ int vr_apply_prepare(vr_context *c) {
     if (const char *e = std::getenv("VR_RAYS_PER_BIN"))
       perBin = (uint32_t)std::max(1, std::atoi(e));
     p.binCap = binCap;
-    uint64_t target = std::max<uint64_t>(cap / perBin, 1);
-    int T1, T2, tiles = 1;
+    c->raysPerBin = perBin;
     uint32_t nb;
-    if (D == 2) {
-      T1 = (int)std::min<uint64_t>(target, 1u << 22);
-      T2 = 1;
-      nb = (uint32_t)T1;
-    } else {
-      T1 = T2 = (int)std::min<double>(4096.0, std::max(1.0, std::ceil(std::sqrt((double)target))));
-      tiles = (T1 + 7) / 8;
-      nb = (uint32_t)tiles * (uint32_t)tiles * 64u;
-    }
+    size_bins(D, cap, perBin, p, nb);
     c->numBins = nb;
-    p.binT1 = T1;
-    p.binT2 = T2;
-    p.binTiles = tiles;
     const size_t slots = (size_t)nb * binCap + cap; // bins + overflow region
     c->slotStride = slots;
     const size_t recFloats = c->absorb ? 8 : 8 + 2 * VR_NPRE; // 32 B, or 32 B + 8 raw outputs
     VR_HIP(c, c->dSlotRec.ensure(slots * recFloats));
     VR_HIP(c, c->dBinCount.ensure((size_t)nb + 1));
+    VR_HIP(c, c->dProbe.ensure(4));
     if (c->overlap) {
       VR_HIP(c, c->dSlotRec2.ensure(slots * recFloats));
       VR_HIP(c, c->dBinCount2.ensure((size_t)nb + 1));
@@ -740,6 +734,8 @@ int vr_apply_prepare(vr_context *c) {
   p.slotTape = c->absorb ? nullptr : c->dSlotTape.p;
   p.binCount = c->dBinCount.p;
   p.idxList = nullptr;
+  p.keyPlane = nullptr;
+  p.probeAcc = nullptr;
   p.batchFirst = first;
   p.batchCount = 0;
   p.slotStride = (uint32_t)c->slotStride;
@@ -779,6 +775,8 @@ int vr_apply_prepare(vr_context *c) {
     p.wallHiR = hr + margin;
   }
   p.farCoord = c->ts[3] ? c->geo.minC[c->ts[0]] : c->geo.maxC[c->ts[0]];
+  if (const char *e = std::getenv("VR_KEY_COORD"))
+    p.farCoord = (float)std::atof(e);
   p.invExt1 = (p.hi1 > p.lo1) ? 1.f / (p.hi1 - p.lo1) : 0.f;
   p.invExt2 = (p.hi2 > p.lo2) ? 1.f / (p.hi2 - p.lo2) : 0.f;
   p.packetBudget = 128;
@@ -796,6 +794,21 @@ int vr_apply_prepare(vr_context *c) {
   return VR_OK;
 }
 
+// sort-bin grid for a batch of `count` rays: far-plane cells holding ~perBin rays each
+static void size_bins(int D, uint64_t count, uint32_t perBin, TraceParams &p, uint32_t &numBins) {
+  const uint64_t target = std::max<uint64_t>(count / std::max<uint32_t>(perBin, 1u), 1);
+  if (D == 2) {
+    p.binT1 = (int)std::min<uint64_t>(target, 1u << 22);
+    p.binT2 = 1;
+    p.binTiles = 1;
+    numBins = (uint32_t)p.binT1;
+  } else {
+    p.binT1 = p.binT2 = (int)std::min<double>(4096.0, std::max(1.0, std::ceil(std::sqrt((double)target))));
+    p.binTiles = (p.binT1 + 7) / 8;
+    numBins = (uint32_t)p.binTiles * (uint32_t)p.binTiles * 64u;
+  }
+}
+
 // one batch of the ray stream: generate straight into the sort bins (stream2 when
 // overlapping), then trace
 static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batchNo) {
@@ -803,6 +816,16 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   p.batchFirst = first;
   p.batchCount = count;
   p.chunk = 32; // sort bins one wave pulls per queue access (~1024 rays)
+  uint32_t nbBatch = c->numBins;
+  size_bins(c->geo.D, count, c->raysPerBin, p, nbBatch); // (<= the grid the buffers were sized for)
+  nbBatch = std::min(nbBatch, c->numBins);
+  p.numBins = nbBatch;
+  {
+    // bins per queue grab: ~1024 rays for big batches, but never so many that a small
+    // batch (the probe) is handed to a few waves only
+    const uint64_t waves = (uint64_t)c->grid * (VR_BLOCK / 64);
+    p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, nbBatch / std::max<uint64_t>(waves * 2, 1)));
+  }
   const bool tape = !c->absorb;
   const unsigned slot = c->overlap ? (unsigned)(batchNo & 1) : 0u;
   if (slot) {
@@ -827,7 +850,7 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   // generator (writes the binned stream of this slot: free once batch b-2 is traced)
   if (c->overlap && batchNo >= 2)
     VR_HIP(c, hipStreamWaitEvent(sg, c->evTraced[batchNo - 2], 0));
-  VR_HIP(c, hipMemsetAsync(p.binCount, 0, ((size_t)c->numBins + 1) * 4, sg));
+  VR_HIP(c, hipMemsetAsync(p.binCount, 0, ((size_t)p.numBins + 1) * 4, sg));
   VR_HIP(c, launch_gen(p, c->geo.D, tape, (unsigned)c->numCUs * 8u, sg));
   // tracer
   if (c->overlap) {
@@ -856,7 +879,31 @@ int vr_apply_launch(vr_context *c) {
   if (c->overlap)
     VR_HIP(c, hipStreamWaitEvent(c->stream2, c->ev0, 0));
   c->numBatches = 0;
-  for (uint64_t f = c->rayFirstLaunch; f < c->rayEndLaunch; f += c->batchCap) {
+  uint64_t f = c->rayFirstLaunch;
+  // Probe batch: the first rays of a large launch are traced first (sorted on the far
+  // face of the geometry box) and report where their first segments end; the mean of
+  // that coordinate becomes the sort plane of the remaining batches, so the sort key
+  // predicts the first hit for any surface height, not just for flat geometry.
+  const uint64_t span = c->rayEndLaunch - c->rayFirstLaunch;
+  const uint32_t probeRays = 1u << 16;
+  bool probe = span >= 16ull * probeRays;
+  if (const char *e = std::getenv("VR_NO_PROBE"))
+    if (std::atoi(e))
+      probe = false;
+  c->params.keyPlane = nullptr;
+  c->params.probeAcc = nullptr;
+  if (probe) {
+    VR_HIP(c, hipMemsetAsync(c->dProbe.p, 0, 16, c->stream));
+    c->params.probeAcc = c->dProbe.p;
+    int r = run_batch(c, f, probeRays, c->numBatches);
+    c->params.probeAcc = nullptr;
+    if (r != VR_OK)
+      return r;
+    ++c->numBatches;
+    f += probeRays;
+    c->params.keyPlane = c->dProbe.p;
+  }
+  for (; f < c->rayEndLaunch; f += c->batchCap) {
     const uint32_t cnt = (uint32_t)std::min<uint64_t>(c->batchCap, c->rayEndLaunch - f);
     int r = run_batch(c, f, cnt, c->numBatches);
     if (r != VR_OK)

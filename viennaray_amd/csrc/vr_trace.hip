@@ -100,8 +100,16 @@ __device__ __forceinline__ float fold_unit(float u, int bc) {
 }
 
 template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p, const V3 &org, const V3 &dir) {
+  // sort plane: the mean first-hit coordinate measured by the probe batch of this launch
+  // (the far face of the geometry box until that is known)
+  float keyCoord = p.farCoord;
+  if (p.keyPlane) {
+    const float cnt = p.keyPlane[1];
+    if (cnt > 0.f)
+      keyCoord = p.keyPlane[0] / cnt;
+  }
   const float dr = getc(dir, p.rayDir);
-  float t = (p.farCoord - p.srcCoord) / (fabsf(dr) > 1e-6f ? dr : copysignf(1e-6f, dr == 0.f ? -p.posNeg : dr));
+  float t = (keyCoord - p.srcCoord) / (fabsf(dr) > 1e-6f ? dr : copysignf(1e-6f, dr == 0.f ? -p.posNeg : dr));
   t = (p.debugFlags & 2u) ? 0.f : (t > 0.f ? t : 0.f); // flag 2: key on the origin instead
   const float u1 = fold_unit((getc(org, p.firstDir) + getc(dir, p.firstDir) * t - p.lo1) * p.invExt1, p.bc0);
   int c1 = (int)(u1 * (float)p.binT1);
@@ -309,8 +317,10 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
 //   nothing after the first surface hit is observable and the reflection /
 //   roulette code (and its RNG) is compiled out.
 // ---------------------------------------------------------------------------
+// (SGPR budget: 256-thread blocks per CU = min(8, 800 / (ceil(sgpr/16)*16 + 16)) on gfx950,
+//  MI355X_MICROARCH.md; 80 keeps 8 blocks resident)
 template <int D, int GEO, int PARTICLE, bool ABSORB>
-__global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void trace_kernel(const TraceParams p) {
   constexpr int NPRE = ABSORB ? 0 : VR_NPRE;
   __shared__ float wallS[96];
   __shared__ u64 tape[NPRE > 0 ? (2 * NPRE + 1) * VR_BLOCK : 1]; // 2W+1 slots: see rng_window
@@ -350,6 +360,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
   const unsigned totalBins = p.numBins + (ovCount + p.binCap - 1) / p.binCap;
   unsigned curBin = 0, spanStart = 0, spanEnd = 0, curOff = 0, curCnt = 0, curBase = 0;
   unsigned spanCounts = 0; // lane i: ray count of bin spanStart + i
+  unsigned packetSkip = 0, packetFails = 0; // wave-uniform back-off of packet attempts
   bool exhausted = false;
 
   for (;;) {
@@ -442,13 +453,23 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
     // with a bounded number of node visits: freshly sorted rays, and rays that left the
     // same surface patch, finish well inside the budget; a scattered set of rays
     // exhausts it and is finished lane by lane.
-    const bool usePacket = !(p.debugFlags & 32u) && __popcll(__ballot(active)) >= 8;
+    const bool usePacket = !(p.debugFlags & 32u) && packetSkip == 0 && __popcll(__ballot(active)) >= 8;
     bool packetDone = false;
-    if (usePacket)
+    if (usePacket) {
       packetDone = bvh_hit_packet<GEO>(p, active, org, dir, tnear, h, p.packetBudget);
+      // a wave whose rays have scattered stops paying for hopeless packets for a while
+      packetFails = packetDone ? 0u : (packetFails < 6u ? packetFails + 1u : 6u);
+      packetSkip = packetDone ? 0u : (1u << packetFails) - 1u;
+    } else if (packetSkip) {
+      --packetSkip;
+    }
     if (active && !packetDone)
       bvh_hit_lane<GEO>(p, org, dir, tnear, h);
-    (void)fresh;
+    const bool wasFresh = fresh;
+    fresh = false;
+    // merge same-disk credits of the wave into one atomic when that is likely to pay: rays
+    // of a packet, or a geometry so small that every wave hammers the same few accumulators
+    const bool aggregate = packetDone || p.numPrims < 16384u;
 
     if (active) {
       // ---- the reference's state machine for this segment (rayTraceKernel.hpp:169-335) ----
@@ -503,6 +524,10 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
           } else {
             geomNormal = mk(prims[4 * h.pos + 1].w, prims[4 * h.pos + 2].w, prims[4 * h.pos + 3].w);
           }
+          if (p.probeAcc && wasFresh) { // probe launch: where do first segments end?
+            atomicAdd(&p.probeAcc[0], getc(hitPoint, p.rayDir));
+            atomicAdd(&p.probeAcc[1], 1.f);
+          }
           const bool backfaceHit = vdot(rayDirection, geomNormal) > 0.f; // :224
           if (backfaceHit) {
             if (GEO == 0 && !hitFromBack) { // first back hit of a disk: let through, :235-240
@@ -517,7 +542,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
             const u64 wfx = weight_fx(rayWeight);
             // surfaceCollision, rayParticle.hpp:148-156
             if (!(p.debugFlags & 1u)) {
-              if (usePacket)
+              if (aggregate)
                 credit_aggregated(p.fluxAcc, true, h.pos, wfx);
               else
                 atomicAdd(&p.fluxAcc[h.pos], wfx);
@@ -530,7 +555,7 @@ __global__ __launch_bounds__(VR_BLOCK) void trace_kernel(const TraceParams p) {
                 const float4 c4 = prims[2 * q];
                 const float4 n4 = prims[2 * q + 1];
                 const bool hitN = local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u);
-                if (usePacket)
+                if (aggregate)
                   credit_aggregated(p.fluxAcc, hitN, q, wfx);
                 else if (hitN)
                   atomicAdd(&p.fluxAcc[q], wfx);
