@@ -695,7 +695,7 @@ int vr_apply_prepare(vr_context *c) {
     c->numBins = nb;
     const size_t slots = (size_t)nb * binCap + cap; // bins + overflow region
     c->slotStride = slots;
-    const size_t recFloats = c->absorb ? 8 : 8 + 2 * VR_NPRE; // 32 B, or 32 B + 8 raw outputs
+    const size_t recFloats = c->absorb ? 8 : 12; // 32 B, or 32 B + the 16-B RNG cursors
     VR_HIP(c, c->dSlotRec.ensure(slots * recFloats));
     VR_HIP(c, c->dBinCount.ensure((size_t)nb + 1));
     VR_HIP(c, c->dProbe.ensure(4));
@@ -782,6 +782,9 @@ int vr_apply_prepare(vr_context *c) {
   p.packetBudget = 128;
   if (const char *e = std::getenv("VR_PACKET_BUDGET"))
     p.packetBudget = (uint32_t)std::max(0, std::atoi(e));
+  p.packetRatio = 3;
+  if (const char *e = std::getenv("VR_PACKET_RATIO"))
+    p.packetRatio = (uint32_t)std::max(1, std::atoi(e));
   p.debugFlags = 0;
   if (const char *e = std::getenv("VR_DEBUG_FLAGS"))
     p.debugFlags = (uint32_t)std::atoi(e);

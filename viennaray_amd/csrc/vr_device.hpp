@@ -48,11 +48,11 @@ __device__ __forceinline__ void vnormalize(V3 &a) {
 // expensive; on the GPU the stream is evaluated lazily from its recurrence
 //   s[0] = seed, s[j] = 6364136223846793005 (s[j-1] ^ s[j-1]>>62) + j  (j < 312)
 //   s[n+312] = s[n+156] ^ tw(s[n], s[n+1]),  output k = temper(s[k+312])
-// Tier 1: the first VR_TAPE outputs need s[0..VR_TAPE] and s[156..156+VR_TAPE):
-//   one 172-step pass of the seeding recurrence, kept in registers, written to
-//   a per-lane LDS tape (bank-conflict free: [slot][lane] layout).
-// Tier 2: a ray that draws more builds the whole 312-word state in a per-lane
-//   global scratch slab ([word][lane] so a wave's accesses coalesce) and
+// Tier 1: outputs 0..155 depend on seeding words only (s[k], s[k+1], s[k+156]); the
+//   generator reaches s[156] once per ray (the unavoidable 156 sequential steps) and
+//   from there every draw advances two cursors by one step each (struct Rng below).
+// Tier 2: a ray that draws more than 156 numbers builds the whole 312-word state in a
+//   per-lane global scratch slab ([word][lane] so a wave's accesses coalesce) and
 //   continues with the textbook block twist.
 // ---------------------------------------------------------------------------
 typedef unsigned long long u64;
@@ -81,45 +81,41 @@ __device__ __forceinline__ u64 mt_temper(u64 v) {
   return v;
 }
 
+// Streaming form of the first 156 outputs: output k = temper(s[k+156] ^ tw(s[k], s[k+1]))
+// depends on three words of the SEEDING recurrence only, and both cursors advance by one
+// mt_step per draw.  A ray therefore carries {k, lo = s[k], hi = s[k+156]} (16 B + a
+// counter) and every draw costs two 64-bit multiply-adds — no tape, no LDS, no state
+// array — until draw 156, where the full 312-word state is needed (tier 2).
 struct Rng {
   unsigned seed;   // engine seed (32 bit)
   unsigned k;      // index of the next output
-  unsigned k0;     // index of the output held in tape slot 0
-  unsigned nTape;  // number of outputs in the tape
   unsigned pos;    // tier 2: position in the 312-word block, 0xFFFFFFFF = not built
-  u64 *tape;       // LDS, this lane's column: tape[slot * VR_BLOCK]
+  u64 lo, hi;      // s[k], s[k+156] while k < 156
   u64 *scratch;    // global, this lane's column: scratch[word * 64]
 };
 
-__device__ __forceinline__ void rng_init(Rng &r, unsigned seed, u64 *tapeLane, u64 *scratchLane) {
+__device__ __forceinline__ void rng_resume(Rng &r, unsigned seed, unsigned k, u64 lo, u64 hi) {
   r.seed = seed;
-  r.k = 0;
-  r.k0 = 0;
-  r.nTape = VR_TAPE;
+  r.k = k;
   r.pos = 0xFFFFFFFFu;
-  r.tape = tapeLane;
-  r.scratch = scratchLane;
-  u64 w[VR_TAPE + 1];
+  r.lo = lo;
+  r.hi = hi;
+}
+
+// cold start: 156 steps of the recurrence to reach s[156]
+__device__ __forceinline__ void rng_init(Rng &r, unsigned seed, u64 *scratchLane) {
   u64 x = seed;
-  w[0] = x;
-#pragma unroll
-  for (int j = 1; j <= VR_TAPE; ++j) {
-    x = mt_step(x, j);
-    w[j] = x;
-  }
 #pragma unroll 4
-  for (int j = VR_TAPE + 1; j < 156; ++j)
+  for (int j = 1; j <= 156; ++j)
     x = mt_step(x, j);
-#pragma unroll
-  for (int i = 0; i < VR_TAPE; ++i) {
-    x = mt_step(x, 156 + i);
-    tapeLane[i * VR_BLOCK] = mt_temper(mt_twist(w[i], w[i + 1], x));
-  }
+  rng_resume(r, seed, 0, (u64)seed, x);
+  r.scratch = scratchLane;
 }
 
 // First K outputs of the engine, all in registers (static indexing): what the
-// generator needs when the number of draws is known at compile time.
-template <int K> __device__ __forceinline__ void mt_first_outputs(unsigned seed, u64 (&out)[K]) {
+// generator needs when the number of draws is known at compile time.  Also returns the
+// streaming cursors {s[K], s[K+156]} for the draws that follow.
+template <int K> __device__ __forceinline__ void mt_first_outputs(unsigned seed, u64 (&out)[K], u64 &lo, u64 &hi) {
   u64 w[K + 1];
   u64 x = seed;
   w[0] = x;
@@ -136,6 +132,8 @@ template <int K> __device__ __forceinline__ void mt_first_outputs(unsigned seed,
     x = mt_step(x, 156 + i);
     out[i] = mt_temper(mt_twist(w[i], w[i + 1], x));
   }
+  lo = w[K];
+  hi = mt_step(x, 156 + K);
 }
 
 __device__ __noinline__ void rng_tier2_build(Rng &r) {
@@ -152,7 +150,6 @@ __device__ __noinline__ void rng_tier2_build(Rng &r) {
 __device__ __noinline__ void rng_tier2_twist(Rng &r) {
   u64 *s = r.scratch;
   u64 cur = s[0];
-  const u64 first = cur;
   for (int i = 0; i < 156; ++i) {
     u64 nxt = s[(i + 1) * 64];
     s[i * 64] = mt_twist(cur, nxt, s[(i + 156) * 64]);
@@ -163,55 +160,23 @@ __device__ __noinline__ void rng_tier2_twist(Rng &r) {
     s[i * 64] = mt_twist(cur, nxt, s[(i - 156) * 64]);
     cur = nxt;
   }
-  (void)first;
   s[311 * 64] = mt_twist(cur, s[0], s[155 * 64]);
 }
 
-// Tier 1b: refill the LDS tape with outputs [k0, k0 + W) of the engine, for k0 + W <= 156,
-// by re-walking the seeding recurrence (k0 + 155 + W steps) and keeping only the
-// 2W + 1 state words those outputs depend on: s[k0 .. k0+W] and s[k0+156 .. k0+155+W].
-// No global memory, ~1/3 of the work of building and twisting the full 312-word state.
-// The tape must have 2W + 1 slots: W outputs land in slots 0..W-1.
-template <int W> __device__ __noinline__ void rng_window(Rng &r, unsigned k0) {
-  u64 *t = r.tape;
-  u64 x = r.seed;
-  if (k0 == 0)
-    t[0] = x;
-  const unsigned last = k0 + 155u + (unsigned)W;
-  for (unsigned j = 1; j <= last; ++j) {
-    x = mt_step(x, j);
-    if (j >= k0 && j <= k0 + (unsigned)W)
-      t[(j - k0) * VR_BLOCK] = x;                       // low words, slots 0..W
-    else if (j >= k0 + 156u)
-      t[((unsigned)W + 1u + (j - k0 - 156u)) * VR_BLOCK] = x; // high words, slots W+1..2W
-  }
-#pragma unroll
-  for (int i = 0; i < W; ++i) {
-    const u64 a = t[i * VR_BLOCK], b = t[(i + 1) * VR_BLOCK], c = t[(W + 1 + i) * VR_BLOCK];
-    t[i * VR_BLOCK] = mt_temper(mt_twist(a, b, c));
-  }
-  r.k0 = k0;
-  r.nTape = W;
-}
-
-// WINDOW > 0: the tape has 2*WINDOW+1 slots and may be refilled by rng_window
-template <int WINDOW = 0> __device__ __forceinline__ u64 rng_next(Rng &r, unsigned &tier2Count) {
-  if (r.k - r.k0 < r.nTape) {
-    u64 v = r.tape[(r.k - r.k0) * VR_BLOCK];
-    ++r.k;
-    return v;
-  }
-  if (WINDOW > 0 && r.pos == 0xFFFFFFFFu && r.k + (unsigned)WINDOW <= 156u) {
-    rng_window<(WINDOW > 0 ? WINDOW : 1)>(r, r.k);
-    u64 v = r.tape[0];
+__device__ __forceinline__ u64 rng_next(Rng &r, unsigned &tier2Count) {
+  if (r.k < 156u) { // (tier 2 is only ever built at k >= 156)
+    const u64 lo1 = mt_step(r.lo, r.k + 1u);
+    const u64 v = mt_temper(mt_twist(r.lo, lo1, r.hi));
+    r.lo = lo1;
+    r.hi = mt_step(r.hi, r.k + 157u); // (meaningless after k = 155; never read again)
     ++r.k;
     return v;
   }
   if (r.pos == 0xFFFFFFFFu) {
     rng_tier2_build(r);
     rng_tier2_twist(r);
-    unsigned skip = r.k; // outputs already consumed from the tape
-    while (skip >= 312u) { // (only after > 312 rejected source samples)
+    unsigned skip = r.k; // outputs already consumed by the streaming tier
+    while (skip >= 312u) {
       rng_tier2_twist(r);
       skip -= 312u;
     }
@@ -424,20 +389,29 @@ typedef const vf4 __attribute__((address_space(4))) *ConstF4;
 // `budget` bounds the number of node visits: a packet whose rays turn out to be
 // incoherent (union of paths much larger than one path) gives up and returns false;
 // the hits found so far are real hits and stay in `h`, the caller finishes with the
-// per-lane traversal.
+// per-lane traversal.  Besides the hard budget the walk keeps a running efficiency
+// figure in scalar registers: `wants` = sum over visited nodes of the lanes whose own
+// box test passed.  wants / lanes is the mean length of ONE ray's path; when the union
+// walked so far exceeds `ratio` times that (plus a start-up allowance) the per-lane
+// traversal is cheaper and the packet gives up (small scenes never reach the hard
+// budget, so this is what protects them).
 template <int GEO>
 __device__ __forceinline__ bool bvh_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
-                                               HitRec &h, unsigned budget) {
+                                               HitRec &h, unsigned budget, unsigned ratio) {
   if (p.numPrims == 0)
     return true;
+  const unsigned lanes = (unsigned)__popcll(__ballot(part));
+  unsigned wants = 16u * lanes; // start-up allowance: 16 visits
+  unsigned visits = 0;
   ConstF4 nodes = (ConstF4)(p.nodes);
   ConstF4 prims = (ConstF4)(p.prims);
   const V3 inv = safe_inverse(d);
   const V3 oi = V3{o.x * inv.x, o.y * inv.y, o.z * inv.z};
   unsigned node = 0; // wave-uniform
   while (node != VR_END) {
-    if (budget-- == 0u)
+    if (visits == budget || visits * lanes > ratio * wants)
       return false;
+    ++visits;
     const vf4 q0 = nodes[2 * node];
     const vf4 q1 = nodes[2 * node + 1];
     const float tx0 = __builtin_fmaf(q0.x, inv.x, -oi.x), tx1 = __builtin_fmaf(q1.x, inv.x, -oi.x);
@@ -447,7 +421,9 @@ __device__ __forceinline__ bool bvh_hit_packet(const TraceParams &p, bool part, 
     const float tExit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), h.t));
     const unsigned link = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
     const unsigned esc = __builtin_amdgcn_readfirstlane(__float_as_uint(q1.w));
-    if (__ballot(part && tEntry <= tExit)) {
+    const unsigned long long want = __ballot(part && tEntry <= tExit);
+    wants += (unsigned)__popcll(want);
+    if (want) {
       if (link & VR_LEAF) {
         const unsigned first = link & VR_LEAF_FIRST_MASK;
         const unsigned cnt = (link >> 27) & 15u;

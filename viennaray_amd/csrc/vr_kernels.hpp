@@ -6,7 +6,7 @@
 
 namespace vr {
 
-hipError_t launch_gen(const TraceParams &p, int D, bool withTape, unsigned maxBlocks, hipStream_t s);
+hipError_t launch_gen(const TraceParams &p, int D, bool keepRng, unsigned maxBlocks, hipStream_t s);
 hipError_t launch_scan(unsigned *data, unsigned n, unsigned *tmp, hipStream_t s);
 hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, bool absorb, unsigned grid,
                         hipStream_t s);

@@ -5,20 +5,20 @@
 // gives the same flux; the GPU path is therefore organised as an HBM-resident
 // RAY STREAM, processed in batches:
 //
-//   gen_kernel      one lane per ray index: per-ray mt19937_64 (lazy, tier 1),
-//                   power-cosine source sample -> 32-byte ray record (+ the next
-//                   VR_NPRE raw engine outputs when the particle keeps going
-//                   after a hit), source-plane cell of the origin, histogram.
-//   scan kernels    exclusive scan of the cell histogram.
-//   scatter_kernel  counting sort of the records by (Morton-ordered) cell, so a
-//                   wavefront's 64 rays start in the same neighbourhood: their
-//                   BVH node / primitive loads hit the same cache lines and their
+//   gen_kernel      one lane per ray index: per-ray mt19937_64 (lazy, streaming),
+//                   power-cosine source sample -> 32-byte ray record (+ the 16-byte
+//                   RNG cursors when the particle keeps going after a hit), written
+//                   DIRECTLY into the sort bin of the cell where the ray crosses the
+//                   sort plane (bin cursor = one atomic; no separate sort pass), so a
+//                   wavefront's 64 rays end in the same neighbourhood: their BVH node
+//                   / primitive fetches are wave-uniform (scalar loads) and their
 //                   traversal loops stay converged.
-//   trace_kernel    persistent wavefronts pull sorted rays; a lane whose ray
-//                   ends pulls the next one (wave-wide compaction by ballot +
-//                   prefix popcount), so bounce chains of different length do
-//                   not idle the wave.  Per segment: closest hit (stackless BVH
-//                   + boundary walls), then the reference's state machine
+//   trace_kernel    persistent wavefronts pull bins; a lane whose ray ends pulls
+//                   the next one (wave-wide compaction by ballot + prefix
+//                   popcount), so bounce chains of different length do not idle
+//                   the wave.  Per segment: closest hit (wave-uniform packet
+//                   traversal with per-lane fallback, stackless BVH + boundary
+//                   walls), then the reference's state machine
 //                   (rayTraceKernel.hpp:155-335).
 #include <hip/hip_runtime.h>
 
@@ -131,8 +131,9 @@ template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p
 // Writes the ray record straight into its sort bin (no separate sort pass): the bin's
 // cursor hands out one of p.binCap slots; a ray whose bin is full goes to the
 // overflow region, which is traced after the bins.  Returns the record slot.
-template <int D, int NPRE>
-__device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, const V3 &o, const V3 &d, unsigned k) {
+template <int D, bool KEEP>
+__device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, const V3 &o, const V3 &d, unsigned k,
+                                              u64 lo, u64 hi) {
   unsigned slot = i;
   if (p.binCount && !(p.debugFlags & 64u)) { // flag 64: timing experiment, no binning
     const unsigned b = bin_of<D>(p, o, project_dir<D>(d));
@@ -142,62 +143,45 @@ __device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, 
     else
       slot = p.numBins * p.binCap + atomicAdd(&p.binCount[p.numBins], 1u); // < ovCap by construction
   }
-  // record = {A, B} (32 B) [+ VR_NPRE raw engine outputs (64 B) when the particle keeps going]
-  float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + (size_t)(NPRE > 0 ? 2 + NPRE / 2 : 2) * slot;
+  // record = {A, B} (32 B) [+ the RNG cursors {s[k], s[k+156]} (16 B) when the particle keeps going]
+  float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + (size_t)(KEEP ? 3 : 2) * slot;
   rec[0] = make_float4(o.x, o.y, o.z, d.x);
   rec[1] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(k));
+  if (KEEP)
+    *reinterpret_cast<ulonglong2 *>(rec + 2) = make_ulonglong2(lo, hi);
   return slot;
 }
 
-// Fixed number of source draws (no tilted primary direction): the K = draws +
-// NPRE engine outputs a ray needs are produced straight into registers — no LDS
-// tape, no tier 2 — by one 156+K-step pass of the seeding recurrence.
-template <int D, int NPRE> __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
+// Fixed number of source draws (no tilted primary direction): the NS engine outputs
+// the source sample needs are produced straight into registers by one 156+NS-step pass
+// of the seeding recurrence, which also leaves the streaming cursors for the trace kernel.
+template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
   constexpr int NS = D == 3 ? 4 : 3;
-  constexpr int K = NS + NPRE;
   for (unsigned i = blockIdx.x * VR_BLOCK + threadIdx.x; i < p.batchCount; i += gridDim.x * VR_BLOCK) {
     const unsigned long long idx = p.idxList ? p.idxList[i] : p.batchFirst + i;
-    u64 out[K];
-    mt_first_outputs<K>(tea3((unsigned)idx, p.seed), out);
+    u64 out[NS], lo, hi;
+    mt_first_outputs<NS>(tea3((unsigned)idx, p.seed), out, lo, hi);
     int k = 0;
     V3 o, d;
     source_sample<D>(p, [&]() { return out[k++]; }, o, d); // k is a compile-time sequence after unrolling
-    const unsigned slot = gen_store<D, NPRE>(p, i, o, d, (unsigned)NS);
-    if (NPRE > 0) {
-      ulonglong2 *tp = reinterpret_cast<ulonglong2 *>(reinterpret_cast<float4 *>(p.slotRec) +
-                                                        (size_t)(2 + NPRE / 2) * slot + 2);
-#pragma unroll
-      for (int s = 0; s < NPRE / 2; ++s)
-        tp[s] = make_ulonglong2(out[NS + 2 * s], out[NS + 2 * s + 1]);
-    }
+    gen_store<D, KEEP>(p, i, o, d, (unsigned)NS, lo, hi);
   }
 }
 
 // General generator (tilted primary direction: the rejection loop makes the number
-// of draws data dependent): LDS tape of the first VR_TAPE outputs + tier 2.
-template <int D, int NPRE> __global__ __launch_bounds__(VR_BLOCK) void gen_basis_kernel(const TraceParams p) {
-  __shared__ u64 tape[VR_TAPE * VR_BLOCK];
+// of draws data dependent): the streaming generator from draw 0 (+ tier 2).
+template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_basis_kernel(const TraceParams p) {
   const unsigned tid = threadIdx.x;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6; // physical wave of this (bounded) grid
   u64 *scratchLane = p.rngScratch + (size_t)gwave * (312u * 64u) + (tid & 63u);
   for (unsigned i = blockIdx.x * VR_BLOCK + tid; i < p.batchCount; i += gridDim.x * VR_BLOCK) {
     const unsigned long long idx = p.idxList ? p.idxList[i] : p.batchFirst + i;
     Rng rng;
-    rng_init(rng, tea3((unsigned)idx, p.seed), tape + tid, scratchLane);
+    rng_init(rng, tea3((unsigned)idx, p.seed), scratchLane);
     unsigned t2 = 0;
     V3 o, d;
     source_sample<D>(p, [&]() { return rng_next(rng, t2); }, o, d);
-    const unsigned slot = gen_store<D, NPRE>(p, i, o, d, rng.k);
-    if (NPRE > 0) {
-      ulonglong2 *tp = reinterpret_cast<ulonglong2 *>(reinterpret_cast<float4 *>(p.slotRec) +
-                                                        (size_t)(2 + NPRE / 2) * slot + 2);
-#pragma unroll
-      for (int s = 0; s < NPRE / 2; ++s) {
-        const u64 a = rng_next(rng, t2);
-        const u64 b = rng_next(rng, t2);
-        tp[s] = make_ulonglong2(a, b);
-      }
-    }
+    gen_store<D, KEEP>(p, i, o, d, rng.k, rng.lo, rng.hi); // (k >= 156: the trace kernel rebuilds tier 2 from the seed)
   }
 }
 
@@ -265,8 +249,8 @@ template <int D> __device__ __forceinline__ V3 reflect_diffuse(const V3 &n, Rng 
   float x, y;
   double x2py2;
   do {
-    x = canon_f32(rng_next<VR_NPRE>(rng, t2)) * 2.0f + -1.0f;
-    y = canon_f32(rng_next<VR_NPRE>(rng, t2)) * 2.0f + -1.0f;
+    x = canon_f32(rng_next(rng, t2)) * 2.0f + -1.0f;
+    y = canon_f32(rng_next(rng, t2)) * 2.0f + -1.0f;
     x2py2 = (double)(x * x + y * y);
   } while (x2py2 >= 1.);
   const double tmp = 2. * sqrt(1. - x2py2);
@@ -321,9 +305,7 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
 //  MI355X_MICROARCH.md; 80 keeps 8 blocks resident)
 template <int D, int GEO, int PARTICLE, bool ABSORB>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void trace_kernel(const TraceParams p) {
-  constexpr int NPRE = ABSORB ? 0 : VR_NPRE;
   __shared__ float wallS[96];
-  __shared__ u64 tape[NPRE > 0 ? (2 * NPRE + 1) * VR_BLOCK : 1]; // 2W+1 slots: see rng_window
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
@@ -343,12 +325,8 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
   bool hitFromBack = false;
   bool fresh = false; // first segment of a ray pulled from the sorted stream
   Rng rng;
-  rng.tape = tape + tid;
+  rng_resume(rng, 0u, 0u, 0ull, 0ull);
   rng.scratch = p.rngScratch + (size_t)gwave * (312u * 64u) + lane;
-  rng.nTape = NPRE;
-  rng.k = rng.k0 = 0;
-  rng.pos = 0xFFFFFFFFu;
-  rng.seed = 0;
   // counters
   unsigned cTraces = 0, cNongeo = 0, cGeo = 0, cBoundary = 0, cRefl = 0, cTerm = 0, cTier2 = 0;
   // wave-uniform cursor over the sort bins: [curBin, spanEnd) is the span of (virtual)
@@ -410,7 +388,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
       const unsigned avail = curCnt - curOff;
       if (!active && rank < avail) {
         const unsigned j = curBase + curOff + rank;
-        constexpr unsigned REC = NPRE > 0 ? 2 + NPRE / 2 : 2; // float4 per record
+        constexpr unsigned REC = ABSORB ? 2 : 3; // float4 per record
         const float4 a = rayAB[REC * (size_t)j];
         const float4 b = rayAB[REC * (size_t)j + 1];
         org = mk(a.x, a.y, a.z);
@@ -424,17 +402,8 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
         active = true;
         if (!ABSORB) {
           const unsigned idxOff = __float_as_uint(b.z);
-          rng.seed = tea3((unsigned)(p.batchFirst + idxOff), p.seed);
-          rng.k = rng.k0 = __float_as_uint(b.w);
-          rng.nTape = NPRE;
-          rng.pos = 0xFFFFFFFFu;
-          const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(rayAB + REC * (size_t)j + 2);
-#pragma unroll
-          for (int s = 0; s < NPRE / 2; ++s) {
-            const ulonglong2 v = tp[s];
-            tape[(2 * s) * VR_BLOCK + tid] = v.x;
-            tape[(2 * s + 1) * VR_BLOCK + tid] = v.y;
-          }
+          const ulonglong2 cur = *reinterpret_cast<const ulonglong2 *>(rayAB + REC * (size_t)j + 2);
+          rng_resume(rng, tea3((unsigned)(p.batchFirst + idxOff), p.seed), __float_as_uint(b.w), cur.x, cur.y);
         }
       }
       const unsigned nIdle = __popcll(idle);
@@ -456,7 +425,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
     const bool usePacket = !(p.debugFlags & 32u) && packetSkip == 0 && __popcll(__ballot(active)) >= 8;
     bool packetDone = false;
     if (usePacket) {
-      packetDone = bvh_hit_packet<GEO>(p, active, org, dir, tnear, h, p.packetBudget);
+      packetDone = bvh_hit_packet<GEO>(p, active, org, dir, tnear, h, p.packetBudget, p.packetRatio);
       // a wave whose rays have scattered stops paying for hopeless packets for a while
       packetFails = packetDone ? 0u : (packetFails < 6u ? packetFails + 1u : 6u);
       packetSkip = packetDone ? 0u : (1u << packetFails) - 1u;
@@ -588,7 +557,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
                   bool reflect = true;
                   if (!(rayWeight >= lowerThreshold)) {
                     const double killProbability = 1.0 - (double)(rayWeight / renewWeight);
-                    if (canon_f64(rng_next<VR_NPRE>(rng, cTier2)) < killProbability)
+                    if (canon_f64(rng_next(rng, cTier2)) < killProbability)
                       reflect = false;
                     else
                       rayWeight = renewWeight;
@@ -625,22 +594,22 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
 // ---------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------
-hipError_t launch_gen(const TraceParams &p, int D, bool withTape, unsigned maxBlocks, hipStream_t s) {
+hipError_t launch_gen(const TraceParams &p, int D, bool keepRng, unsigned maxBlocks, hipStream_t s) {
   unsigned grid = (p.batchCount + VR_BLOCK - 1) / VR_BLOCK;
   if (grid == 0)
     return hipSuccess;
   if (grid > maxBlocks)
     grid = maxBlocks; // grid-stride; bounds the tier-2 slabs to grid waves
-  const int key = (p.useBasis ? 4 : 0) | (D == 2 ? 0 : 2) | (withTape ? 1 : 0);
+  const int key = (p.useBasis ? 4 : 0) | (D == 2 ? 0 : 2) | (keepRng ? 1 : 0);
   switch (key) {
-  case 0: hipLaunchKernelGGL((gen_kernel<2, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 1: hipLaunchKernelGGL((gen_kernel<2, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 2: hipLaunchKernelGGL((gen_kernel<3, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 3: hipLaunchKernelGGL((gen_kernel<3, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 4: hipLaunchKernelGGL((gen_basis_kernel<2, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 5: hipLaunchKernelGGL((gen_basis_kernel<2, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 6: hipLaunchKernelGGL((gen_basis_kernel<3, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  default: hipLaunchKernelGGL((gen_basis_kernel<3, VR_NPRE>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 0: hipLaunchKernelGGL((gen_kernel<2, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 1: hipLaunchKernelGGL((gen_kernel<2, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 2: hipLaunchKernelGGL((gen_kernel<3, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 3: hipLaunchKernelGGL((gen_kernel<3, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 4: hipLaunchKernelGGL((gen_basis_kernel<2, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 5: hipLaunchKernelGGL((gen_basis_kernel<2, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  case 6: hipLaunchKernelGGL((gen_basis_kernel<3, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+  default: hipLaunchKernelGGL((gen_basis_kernel<3, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
   }
   return hipGetLastError();
 }
@@ -742,12 +711,10 @@ hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *or
 }
 
 __global__ __launch_bounds__(VR_BLOCK) void debug_rng_kernel(unsigned seed32, unsigned count, u64 *scratch, u64 *out) {
-  __shared__ u64 tape[VR_TAPE * VR_BLOCK];
-  const unsigned tid = threadIdx.x;
-  if (tid != 0)
+  if (threadIdx.x != 0)
     return;
   Rng rng;
-  rng_init(rng, seed32, tape + tid, scratch);
+  rng_init(rng, seed32, scratch);
   unsigned t2 = 0;
   for (unsigned i = 0; i < count; ++i)
     out[i] = rng_next(rng, t2);

@@ -29,13 +29,9 @@ struct Tri {       // boundary wall triangle, Embree's precomputed form
 // Ray stream record (HBM-resident, sorted by source-plane cell before tracing):
 //   32 B: A = {org.x, org.y, org.z, dir.x}   B = {dir.y, dir.z, bits(idx - batchFirst), bits(k)}
 //   k = number of engine outputs the source sampling consumed
-//   tape[s][i] (only for particles that keep going after a hit): raw engine
-//   outputs k .. k+VR_NPRE-1 of ray i, structure-of-arrays by slot
-constexpr int VR_NPRE = 8;
+//   +16 B (only for particles that keep going after a hit): C = {s[k], s[k+156]}, the two
+//   cursors of the streaming mt19937_64 (vr_device.hpp, struct Rng)
 constexpr unsigned VR_BIN_CAP = 64; // record slots per sort bin (one wavefront)
-
-// number of per-ray RNG outputs the generator keeps in its LDS tape (tier 1)
-constexpr int VR_TAPE = 16;
 constexpr int VR_BLOCK = 256;
 
 struct TraceParams {
@@ -84,6 +80,7 @@ struct TraceParams {
   int32_t binT1, binT2;           // cells per axis
   int32_t binTiles;               // 8x8-cell tiles per row (3-D)
   uint32_t packetBudget;          // node visits a packet traversal may spend before giving up
+  uint32_t packetRatio;           // ... and it gives up when union visits > ratio x mean per-ray path
   uint32_t debugFlags;            // VR_DEBUG_FLAGS (timing experiments; 0 in production)
 };
 
