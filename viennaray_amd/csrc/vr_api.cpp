@@ -94,6 +94,10 @@ struct vr_context {
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
   DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
   size_t scratchWaves = 0;
+  // flux accumulators are replicated accReplicas times (power of two, stride accStride
+  // elements); a block credits replica blockIdx & (accReplicas-1): small scenes would
+  // otherwise serialise every credit of the chip on a handful of cache lines
+  uint32_t accReplicas = 1, accStride = 0;
   // device-side setup (vr_setup.hip)
   DevBuf<float> dDisk4, dNormal3, dPoints3, dVerts, dBox, dSBox, dNodeBox;
   DevBuf<uint32_t> dTris, dBounds, dValsA, dValsB, dSortTable, dRangeLo, dRangeHi, dChildL, dChildR, dParentInt,
@@ -418,7 +422,19 @@ static int build_scene(vr_context *c) {
   c->hostNeighborsValid = false;
   VR_HIP(c, c->dLeafOfOrig.ensure(N));
   VR_HIP(c, c->dOrder.ensure(N));
-  VR_HIP(c, c->dFluxAcc.ensure(N));
+  {
+    uint32_t R = 1;
+    if (const char *e = std::getenv("VR_ACC_REPLICAS"))
+      R = (uint32_t)std::max(1, std::atoi(e));
+    else
+      while (R < 64u && (size_t)N * (2u * R) <= (1u << 21))
+        R *= 2u;
+    while (R & (R - 1u)) // power of two
+      R &= R - 1u;
+    c->accReplicas = R;
+    c->accStride = (N + 15u) & ~15u; // replicas start on 128-byte lines
+    VR_HIP(c, c->dFluxAcc.ensure((size_t)c->accStride * R));
+  }
   VR_HIP(c, c->dFluxOrig.ensure(N));
   VR_HIP(c, c->dCounters.ensure(16));
   VR_HIP(c, c->dNbOff.ensure((size_t)N + 1));
@@ -727,6 +743,8 @@ int vr_apply_prepare(vr_context *c) {
   p.primSticking = dStick;
   p.wallTable = c->dWalls.p;
   p.fluxAcc = c->dFluxAcc.p;
+  p.accStride = c->accStride;
+  p.accMask = c->accReplicas - 1u;
   p.counters = c->dCounters.p;
   p.workCounter = c->dCounters.p + 8;
   p.rngScratch = c->dScratch.p;
@@ -876,7 +894,7 @@ int vr_apply_launch(vr_context *c) {
     return fail(c, VR_E_STATE, "vr_apply_launch: call vr_apply_prepare first");
   VR_HIP(c, hipSetDevice(c->device));
   const uint32_t N = c->geo.numPrims;
-  VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)N * 8, c->stream));
+  VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)c->accStride * c->accReplicas * 8, c->stream));
   VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 16 * 8, c->stream));
   VR_HIP(c, hipEventRecord(c->ev0, c->stream));
   if (c->overlap)
@@ -914,7 +932,7 @@ int vr_apply_launch(vr_context *c) {
     ++c->numBatches;
   }
   VR_HIP(c, hipEventRecord(c->ev1, c->stream));
-  VR_HIP(c, launch_gather_flux(c->dFluxAcc.p, c->dLeafOfOrig.p, N, c->fluxOut(), c->stream));
+  VR_HIP(c, launch_gather_flux(c->dFluxAcc.p, c->accStride, c->accReplicas, c->dLeafOfOrig.p, N, c->fluxOut(), c->stream));
   c->launched = true;
   return VR_OK;
 }

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
 
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
   const float4 *__restrict__ rayAB = reinterpret_cast<const float4 *>(p.slotRec);
+  unsigned long long *const fluxAcc = p.fluxAcc + (size_t)(blockIdx.x & p.accMask) * p.accStride; // this block's replica
   const float tnear = 1e-4f; // rayUtil.hpp:229-231
 
   // per-lane ray state
@@ -437,8 +438,8 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
     const bool wasFresh = fresh;
     fresh = false;
     // merge same-disk credits of the wave into one atomic when that is likely to pay: rays
-    // of a packet, or a geometry so small that every wave hammers the same few accumulators
-    const bool aggregate = packetDone || p.numPrims < 16384u;
+    // of a packet (small scenes spread their credits over accumulator replicas instead)
+    const bool aggregate = packetDone;
 
     if (active) {
       // ---- the reference's state machine for this segment (rayTraceKernel.hpp:169-335) ----
@@ -512,9 +513,9 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
             // surfaceCollision, rayParticle.hpp:148-156
             if (!(p.debugFlags & 1u)) {
               if (aggregate)
-                credit_aggregated(p.fluxAcc, true, h.pos, wfx);
+                credit_aggregated(fluxAcc, true, h.pos, wfx);
               else
-                atomicAdd(&p.fluxAcc[h.pos], wfx);
+                atomicAdd(&fluxAcc[h.pos], wfx);
             }
             if (GEO == 0 && !(p.debugFlags & 4u)) {
               // every overlapping neighbour disk is credited the full weight (:271-300)
@@ -525,9 +526,9 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
                 const float4 n4 = prims[2 * q + 1];
                 const bool hitN = local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u);
                 if (aggregate)
-                  credit_aggregated(p.fluxAcc, hitN, q, wfx);
+                  credit_aggregated(fluxAcc, hitN, q, wfx);
                 else if (hitN)
-                  atomicAdd(&p.fluxAcc[q], wfx);
+                  atomicAdd(&fluxAcc[q], wfx);
               }
             }
             if (ABSORB) {
@@ -727,16 +728,22 @@ hipError_t launch_debug_rng(unsigned seed32, unsigned count, unsigned long long 
 }
 
 // un-permute the leaf-ordered accumulators into the caller's primitive order
-__global__ void gather_flux_kernel(const unsigned long long *acc, const unsigned *leafOfOrig, unsigned n,
-                                   unsigned long long *outAcc) {
+__global__ void gather_flux_kernel(const unsigned long long *acc, unsigned stride, unsigned replicas,
+                                   const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n)
-    outAcc[i] = acc[leafOfOrig[i]];
+  if (i < n) {
+    const unsigned q = leafOfOrig[i];
+    unsigned long long s = 0; // (integer sum: replica order is irrelevant)
+    for (unsigned r = 0; r < replicas; ++r)
+      s += acc[(size_t)r * stride + q];
+    outAcc[i] = s;
+  }
 }
 
-hipError_t launch_gather_flux(const unsigned long long *acc, const unsigned *leafOfOrig, unsigned n,
-                              unsigned long long *outAcc, hipStream_t s) {
-  hipLaunchKernelGGL(gather_flux_kernel, dim3((n + 255) / 256), dim3(256), 0, s, acc, leafOfOrig, n, outAcc);
+hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, unsigned replicas,
+                              const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, hipStream_t s) {
+  hipLaunchKernelGGL(gather_flux_kernel, dim3((n + 255) / 256), dim3(256), 0, s, acc, stride, replicas, leafOfOrig, n,
+                     outAcc);
   return hipGetLastError();
 }
 

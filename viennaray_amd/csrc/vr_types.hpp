@@ -43,6 +43,7 @@ struct TraceParams {
   const float *primSticking;  // optional [numPrims] (leaf order) or nullptr
   const float *wallTable;     // 8 x {v0, e1, e2, Ng} = 96 floats
   unsigned long long *fluxAcc;   // [numPrims] leaf order, fixed point 2^-40
+  uint32_t accStride, accMask;   // replica r of the accumulators starts at fluxAcc + r * accStride; r = blockIdx & accMask
   unsigned long long *counters;  // [8]
   unsigned long long *workCounter;
   unsigned long long *rngScratch; // [waves][312][64]
