@@ -427,4 +427,4 @@ def test_host_and_device_builders_agree(monkeypatch):
     monkeypatch.setenv("VR_HOST_BUILD", "1")
     fh, ih, sh = run()
     assert (fd == fh).all() and idv == ih
-    assert sh["maxDepth"] > 0 and sd["nodes"] == 2 * len(p) - 1
+    assert sh["maxDepth"] > 0 and 0 < sd["nodes"] <= 2 * len(p) - 1

@@ -25,7 +25,9 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.cs
         print("  dispatch", disp, k, {c: v for c, v in cs.items()})
 
 # traffic of the dominant kernel per launch (MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 64-B
-# requests of 128-B wide reads as 64 B -> doubled; WRITE_SIZE exact), KB -> bytes
+# requests of 128-B wide reads as 64 B -> doubled; WRITE_SIZE exact), KB -> bytes.
+# A step launches trace_kernel twice: the 65536-ray probe and the main batch; "per launch" is the
+# mean over the MAIN launches (those above 10 % of the largest), the probe's share is < 0.1 %.
 import json
 vals = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -35,10 +37,19 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
             if "trace_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == name:
                 per[r.get("Dispatch_Id")] += float(r.get("Counter_Value", 0))
         if per:
-            vals[name] = sum(per.values()) / len(per)
+            top = max(per.values())
+            main = [v for v in per.values() if v > 0.1 * top]
+            vals[name] = sum(main) / len(main)
 if len(vals) == 2:
     out = {"kernel": "trace_kernel", "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
            "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
-           "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per trace_kernel launch; fabric requests incl. Infinity-Cache hits"}
+           "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per main trace_kernel launch; fabric requests incl. Infinity-Cache hits"}
+    # the workload the numbers belong to (bench.py only quotes them for the same one)
+    try:
+        line = [l for l in open(os.path.join(d, "stats.log")) if l.startswith("{")][-1]
+        cfg = json.loads(line)["config"]
+        out.update(grid=cfg["grid"], rays=cfg["rays_per_gpu"], sticking=cfg["sticking"])
+    except Exception as e:
+        print("no bench line in stats.log:", e)
     print("== traffic:", json.dumps(out))
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"))

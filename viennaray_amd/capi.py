@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libviennaray_amd.so")
+LIB_PATH = os.environ.get("VR_LIB_PATH") or os.path.join(_HERE, "libviennaray_amd.so")  # (override: A/B runs of two builds)
 
 VR_OK, VR_E_INVALID, VR_E_HIP, VR_E_STATE = 0, -1, -2, -3
 

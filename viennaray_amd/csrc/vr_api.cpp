@@ -41,6 +41,10 @@ template <class T> struct DevBuf {
     p = nullptr;
     cap = 0;
   }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); } // (vr_destroy selects the device before the context goes away)
 };
 } // namespace
 
@@ -101,7 +105,12 @@ struct vr_context {
   // device-side setup (vr_setup.hip)
   DevBuf<float> dDisk4, dNormal3, dPoints3, dVerts, dBox, dSBox, dNodeBox;
   DevBuf<uint32_t> dTris, dBounds, dValsA, dValsB, dSortTable, dRangeLo, dRangeHi, dChildL, dChildR, dParentInt,
-      dParentLeaf, dArrive, dOrder;
+      dParentLeaf, dArrive, dOrder, dSubSize, dQNodes;
+  DevBuf<float> dNodesPre;
+  uint32_t numNodes = 0;         // traversal nodes emitted by the builder
+  float qbase[3] = {0, 0, 0}, qscale[3] = {0, 0, 0}; // frame of the 16-byte nodes
+  int builtOrderAxis = -1;       // child order of the resident BVH (source side first)
+  float builtOrderSign = 0.f;
   DevBuf<unsigned long long> dKeysA, dKeysB;
   bool hostOrderValid = false;   // c->bvh.order mirrors dOrder
   bool hostNeighborsValid = false;
@@ -414,6 +423,21 @@ static int ensure_host_neighbors(vr_context *c) {
   return VR_OK;
 }
 
+// 16-byte nodes for the per-lane traversal: frame from the root box (which holds every
+// padded primitive box), two cells of margin so the outward rounding never clamps
+static int quantize_scene(vr_context *c, const float *preNodes, const float *root8) {
+  const float lo[3] = {root8[0], root8[1], root8[2]}, hi[3] = {root8[4], root8[5], root8[6]};
+  for (int k = 0; k < 3; ++k) {
+    const float ext = hi[k] - lo[k];
+    c->qscale[k] = ext > 0.f ? 65531.0f / ext : 0.f;
+    c->qbase[k] = ext > 0.f ? lo[k] - 2.0f / c->qscale[k] : lo[k];
+  }
+  VR_HIP(c, c->dQNodes.ensure((size_t)c->numNodes * 4));
+  VR_HIP(c, launch_quantize_nodes(preNodes, c->numNodes, c->qbase, c->qscale, c->dQNodes.p, c->stream));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
+  return VR_OK;
+}
+
 static int build_scene(vr_context *c) {
   HostGeometry &g = c->geo;
   const uint32_t N = g.numPrims;
@@ -436,7 +460,7 @@ static int build_scene(vr_context *c) {
     VR_HIP(c, c->dFluxAcc.ensure((size_t)c->accStride * R));
   }
   VR_HIP(c, c->dFluxOrig.ensure(N));
-  VR_HIP(c, c->dCounters.ensure(16));
+  VR_HIP(c, c->dCounters.ensure(64));
   VR_HIP(c, c->dNbOff.ensure((size_t)N + 1));
   const char *hb = std::getenv("VR_HOST_BUILD");
   if (hb && std::atoi(hb)) {
@@ -475,11 +499,20 @@ static int build_scene(vr_context *c) {
     VR_HIP(c, hipMemcpyAsync(c->dLeafOfOrig.p, c->leafOfOrig.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
     VR_HIP(c, hipMemcpyAsync(c->dOrder.p, c->bvh.order.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
     VR_HIP(c, hipStreamSynchronize(c->stream));
-    return VR_OK;
+    c->numNodes = c->bvh.numNodes;
+    return quantize_scene(c, c->dNodes.p, c->bvh.nodes.data()); // (host builder: pre-order already)
   }
 
   // ---- device builder ----
   SetupParams s{};
+  s.leafMax = (uint32_t)VR_LEAF_MAX;
+  if (const char *e = std::getenv("VR_LEAF_MAX"))
+    s.leafMax = (uint32_t)std::min(15, std::max(1, std::atoi(e)));
+  s.orderAxis = c->ts[0];                   // rays travel along this axis ...
+  s.orderSign = c->ts[3] ? 1.f : -1.f;      // ... from its max (min) side: that child first
+  if (const char *e = std::getenv("VR_NO_CHILD_ORDER"))
+    if (std::atoi(e))
+      s.orderSign = 0.f;
   s.n = N;
   s.geo = g.geo;
   s.D = g.D;
@@ -514,7 +547,9 @@ static int build_scene(vr_context *c) {
   VR_HIP(c, c->dParentInt.ensure(N));
   VR_HIP(c, c->dParentLeaf.ensure(N));
   VR_HIP(c, c->dArrive.ensure(N));
+  VR_HIP(c, c->dSubSize.ensure(N));
   VR_HIP(c, c->dNodes.ensure(((size_t)2 * N) * 8));
+  VR_HIP(c, c->dNodesPre.ensure(((size_t)2 * N) * 8));
   VR_HIP(c, c->dPrims.ensure((size_t)N * (disk ? 8 : 16)));
   VR_HIP(c, c->dScanTmp.ensure(2 * ((256 * tiles + (size_t)N + 1) / 2048 + 4) + 64));
   s.disk4 = c->dDisk4.p;
@@ -538,7 +573,9 @@ static int build_scene(vr_context *c) {
   s.parentLeaf = c->dParentLeaf.p;
   s.arrive = c->dArrive.p;
   s.nodeBox = c->dNodeBox.p;
+  s.subSize = c->dSubSize.p;
   s.nodes = c->dNodes.p;
+  s.nodesPre = c->dNodesPre.p;
   s.prims = c->dPrims.p;
   s.leafOfOrig = c->dLeafOfOrig.p;
   s.order = c->dOrder.p;
@@ -560,11 +597,18 @@ static int build_scene(vr_context *c) {
     VR_HIP(c, hipMemsetAsync(c->dNbOff.p, 0, ((size_t)N + 1) * 4, c->stream));
     VR_HIP(c, c->dNbIds.ensure(1));
   }
+  float root8[8];
+  uint32_t sz = 0;
+  VR_HIP(c, hipMemcpyAsync(root8, c->dNodesPre.p, sizeof(root8), hipMemcpyDeviceToHost, c->stream));
+  VR_HIP(c, hipMemcpyAsync(&sz, c->dSubSize.p, 4, hipMemcpyDeviceToHost, c->stream));
   VR_HIP(c, hipStreamSynchronize(c->stream));
-  c->bvh.numNodes = 2 * N - 1;
+  c->numNodes = sz & 0x7FFFFFFFu;
+  c->bvh.numNodes = c->numNodes;
   c->bvh.numLeaves = 0;
   c->bvh.maxDepth = 0;
-  return VR_OK;
+  const int rq = quantize_scene(c, c->dNodesPre.p, root8);
+  c->dNodesPre.release(); // (build-time scratch)
+  return rq;
 }
 
 // ---- run ----------------------------------------------------------------------
@@ -633,11 +677,16 @@ int vr_apply_prepare(vr_context *c) {
   }
 
   const uint32_t N = c->geo.numPrims;
+  // the BVH's child order follows the source side: a new source direction rebuilds it
+  if (c->builtOrderAxis != c->ts[0] || c->builtOrderSign != (c->ts[3] ? 1.f : -1.f))
+    c->geometryDirty = true;
   if (c->geometryDirty) {
     int r = build_scene(c);
     if (r != VR_OK)
       return r;
     c->geometryDirty = false;
+    c->builtOrderAxis = c->ts[0];
+    c->builtOrderSign = c->ts[3] ? 1.f : -1.f;
   }
   // per-primitive sticking from the material map (gpu::Particle-style, rayParticle.hpp:208-218)
   if (redoConfig)
@@ -737,6 +786,12 @@ int vr_apply_prepare(vr_context *c) {
   }
 
   p.nodes = c->dNodes.p;
+  p.qnodes = c->dQNodes.p;
+  p.numNodes = c->numNodes;
+  for (int k = 0; k < 3; ++k) {
+    p.qbase[k] = c->qbase[k];
+    p.qscale[k] = c->qscale[k];
+  }
   p.prims = c->dPrims.p;
   p.nbOff = c->dNbOff.p;
   p.nbIds = c->dNbIds.p;
@@ -800,6 +855,12 @@ int vr_apply_prepare(vr_context *c) {
   p.packetBudget = 128;
   if (const char *e = std::getenv("VR_PACKET_BUDGET"))
     p.packetBudget = (uint32_t)std::max(0, std::atoi(e));
+  p.walkPark = 34;
+  if (const char *e = std::getenv("VR_WALK_PARK"))
+    p.walkPark = (uint32_t)std::min(100, std::max(1, std::atoi(e)));
+  p.walkExit = 32;
+  if (const char *e = std::getenv("VR_WALK_EXIT"))
+    p.walkExit = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   p.packetRatio = 3;
   if (const char *e = std::getenv("VR_PACKET_RATIO"))
     p.packetRatio = (uint32_t)std::max(1, std::atoi(e));
@@ -895,7 +956,7 @@ int vr_apply_launch(vr_context *c) {
   VR_HIP(c, hipSetDevice(c->device));
   const uint32_t N = c->geo.numPrims;
   VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)c->accStride * c->accReplicas * 8, c->stream));
-  VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 16 * 8, c->stream));
+  VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64 * 8, c->stream));
   VR_HIP(c, hipEventRecord(c->ev0, c->stream));
   if (c->overlap)
     VR_HIP(c, hipStreamWaitEvent(c->stream2, c->ev0, 0));
@@ -946,6 +1007,19 @@ int vr_apply_finish(vr_context *c) {
   VR_HIP(c, hipStreamSynchronize(c->stream));
   unsigned long long cnt[8];
   VR_HIP(c, hipMemcpy(cnt, c->dCounters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+#ifdef VR_DIAG
+  { // lane-occupancy diagnostics of a -DVR_DIAG build (see vr_trace.hip)
+    unsigned long long dg[32];
+    VR_HIP(c, hipMemcpy(dg, c->dCounters.p + 16, sizeof(dg), hipMemcpyDeviceToHost));
+    static const char *names[16] = {"rounds", "walk steps", "leaf prim tests", "packet visits", "packet prim tests",
+                                    "state machine", "neighbour iters", "reflect iters", "refill reps", "wall init",
+                                    "roulette", "credit", "-", "-", "-", "-"};
+    for (int k = 0; k < 16; ++k)
+      if (dg[2 * k])
+        std::fprintf(stderr, "diag %-18s wave-iters %12llu  lane-iters %14llu  (%.1f lanes)\n", names[k], dg[2 * k],
+                     dg[2 * k + 1], (double)dg[2 * k + 1] / (double)dg[2 * k]);
+  }
+#endif
   float ms = 0.f;
   VR_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   vr_trace_info &i = c->info;

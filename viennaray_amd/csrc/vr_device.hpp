@@ -57,6 +57,26 @@ __device__ __forceinline__ void vnormalize(V3 &a) {
 // ---------------------------------------------------------------------------
 typedef unsigned long long u64;
 
+// -DVR_DIAG: lane-occupancy counters.  DIAG(k) inside any (divergent) region counts one
+// wave-level execution and the lanes that took part; summed into counters[16 + 2k, +1].
+#ifdef VR_DIAG
+#define VR_DIAG_DECL unsigned diagW[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, diagL[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define DIAG(k)                                                                                                        \
+  do {                                                                                                                 \
+    const unsigned long long m_ = __ballot(1);                                                                         \
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1)                                                        \
+      ++diagW[k];                                                                                                      \
+    ++diagL[k];                                                                                                        \
+  } while (0)
+#define VR_DIAG_ARGS , unsigned (&diagW)[12], unsigned (&diagL)[12]
+#define VR_DIAG_PASS , diagW, diagL
+#else
+#define VR_DIAG_DECL
+#define DIAG(k)
+#define VR_DIAG_ARGS
+#define VR_DIAG_PASS
+#endif
+
 __device__ __forceinline__ unsigned tea3(unsigned v0, unsigned v1) {
   unsigned s0 = 0;
 #pragma unroll
@@ -326,32 +346,72 @@ __device__ __forceinline__ void hit_update(HitRec &h, bool ok, float t, unsigned
   }
 }
 
-// geometry, per-lane: every lane walks its own path (incoherent rays)
+// geometry, per-lane: every lane walks its own path (incoherent rays).  Divergent lanes
+// make every node fetch 64 separate requests, so this walk reads the 16-byte nodes:
+// one dwordx4 per visit.  The slab test runs in the quantised frame (ray transformed
+// once per call; per-axis scaling leaves t unchanged); boxes were rounded outwards
+// by more than the rounding of this test, and a box only ever culls.
+// `node` is the lane's cursor (resumable): the loop runs while at least `minLanes`
+// lanes of the wave are still walking, then returns with the stragglers' cursors and
+// closest hits intact.
 template <int GEO>
-__device__ __forceinline__ void bvh_hit_lane(const TraceParams &p, const V3 &o, const V3 &d, float tnear, HitRec &h) {
-  if (p.numPrims == 0)
-    return;
-  const float4 *__restrict__ nodes = reinterpret_cast<const float4 *>(p.nodes);
+__device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
+                                               HitRec &h, unsigned &node, unsigned minLanes VR_DIAG_ARGS) {
+  const uint4 *__restrict__ qnodes = reinterpret_cast<const uint4 *>(p.qnodes);
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
-  const V3 inv = safe_inverse(d);
-  const V3 oi = V3{o.x * inv.x, o.y * inv.y, o.z * inv.z};
-  unsigned node = 0;
-  while (node != VR_END) {
-    const float4 q0 = nodes[2 * node];
-    const float4 q1 = nodes[2 * node + 1];
-    // boxes are padded at build time by more than the rounding of this test
-    const float tx0 = __builtin_fmaf(q0.x, inv.x, -oi.x), tx1 = __builtin_fmaf(q1.x, inv.x, -oi.x);
-    const float ty0 = __builtin_fmaf(q0.y, inv.y, -oi.y), ty1 = __builtin_fmaf(q1.y, inv.y, -oi.y);
-    const float tz0 = __builtin_fmaf(q0.z, inv.z, -oi.z), tz1 = __builtin_fmaf(q1.z, inv.z, -oi.z);
-    const float tEntry = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
-    const float tExit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), h.t));
-    const unsigned link = __float_as_uint(q0.w);
-    const unsigned esc = __float_as_uint(q1.w);
-    if (tEntry <= tExit) {
-      if (link & VR_LEAF) {
-        const unsigned first = link & VR_LEAF_FIRST_MASK;
-        const unsigned cnt = (link >> 27) & 15u;
-        for (unsigned i = 0; i < cnt; ++i) {
+  const V3 inv = safe_inverse(V3{d.x * p.qscale[0], d.y * p.qscale[1], d.z * p.qscale[2]});
+  const V3 oi = V3{(o.x - p.qbase[0]) * p.qscale[0] * inv.x, (o.y - p.qbase[1]) * p.qscale[1] * inv.y,
+                   (o.z - p.qbase[2]) * p.qscale[2] * inv.z};
+  if (!part)
+    node = VR_END;
+  // Two alternating phases ("while-while"): a lane SEARCHES for leaves whose box it hits.
+  // The first such leaf is only remembered (`pend`) and the lane searches on
+  // (speculatively: it may visit nodes the pending leaf's hit would have culled); at a
+  // second leaf it parks on that node.  When a given share of the lanes under way are
+  // parked, or nobody searches any more, the pending leaves' primitives are tested
+  // together.  Testing a leaf the moment one lane reaches it would run the (long)
+  // primitive test with a handful of lanes on almost every step.
+  unsigned pend = 0u; // pending leaf link (VR_LEAF bit set) or 0
+  for (;;) {
+    bool parked = false;
+    for (;;) {
+      const bool search = node < p.numNodes && !parked;
+      const unsigned long long sm = __ballot(search);
+      if (!sm)
+        break;
+      const unsigned long long km = __ballot(parked);
+      if (100u * (unsigned)__popcll(km) >= p.walkPark * (unsigned)__popcll(km | sm))
+        break;
+      if (search) {
+        DIAG(1);
+        const uint4 nd = qnodes[node];
+        const float lx = (float)(nd.x & 0xFFFFu), ly = (float)(nd.x >> 16), lz = (float)(nd.y & 0xFFFFu);
+        const float hx = (float)(nd.y >> 16), hy = (float)(nd.z & 0xFFFFu), hz = (float)(nd.z >> 16);
+        const float tx0 = __builtin_fmaf(lx, inv.x, -oi.x), tx1 = __builtin_fmaf(hx, inv.x, -oi.x);
+        const float ty0 = __builtin_fmaf(ly, inv.y, -oi.y), ty1 = __builtin_fmaf(hy, inv.y, -oi.y);
+        const float tz0 = __builtin_fmaf(lz, inv.z, -oi.z), tz1 = __builtin_fmaf(hz, inv.z, -oi.z);
+        const float tEntry = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
+        const float tExit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), h.t));
+        const unsigned link = nd.w;
+        const bool leaf = (link & VR_LEAF) != 0u;
+        const bool hitBox = tEntry <= tExit;
+        if (hitBox && leaf) {
+          if (pend == 0u)
+            pend = link;
+          else
+            parked = true; // second leaf: wait here (the node is visited again afterwards)
+        }
+        // pre-order: first child of an internal node / escape of a leaf = next node
+        if (!parked)
+          node = (hitBox || leaf) ? node + 1u : link;
+      }
+    }
+    if (__ballot(pend != 0u)) {
+      const unsigned first = pend & VR_LEAF_FIRST_MASK;
+      const unsigned cnt = pend ? (pend >> 27) & 15u : 0u;
+      for (unsigned i = 0; __ballot(i < cnt); ++i) {
+        if (i < cnt) {
+          DIAG(2);
           const unsigned q = first + i;
           float t;
           if (GEO == 0) {
@@ -366,14 +426,20 @@ __device__ __forceinline__ void bvh_hit_lane(const TraceParams &p, const V3 &o, 
             hit_update(h, ok, t, __float_as_uint(a.w), q);
           }
         }
-        node = esc;
-      } else {
-        node = link;
       }
-    } else {
-      node = esc;
+      pend = 0u;
     }
+    if ((unsigned)__popcll(__ballot(node < p.numNodes)) < minLanes)
+      break;
   }
+}
+
+// one ray, whole walk (diagnostic entry points)
+template <int GEO>
+__device__ __forceinline__ void bvh_hit_lane(const TraceParams &p, const V3 &o, const V3 &d, float tnear, HitRec &h) {
+  unsigned node = 0u;
+  VR_DIAG_DECL
+  bvh_walk_lanes<GEO>(p, true, o, d, tnear, h, node, 1u VR_DIAG_PASS);
 }
 
 // geometry, wave-uniform ("packet"): the 64 rays of a wavefront that were sorted
@@ -397,7 +463,7 @@ typedef const vf4 __attribute__((address_space(4))) *ConstF4;
 // budget, so this is what protects them).
 template <int GEO>
 __device__ __forceinline__ bool bvh_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
-                                               HitRec &h, unsigned budget, unsigned ratio) {
+                                               HitRec &h, unsigned budget, unsigned ratio VR_DIAG_ARGS) {
   if (p.numPrims == 0)
     return true;
   const unsigned lanes = (unsigned)__popcll(__ballot(part));
@@ -412,6 +478,9 @@ __device__ __forceinline__ bool bvh_hit_packet(const TraceParams &p, bool part, 
     if (visits == budget || visits * lanes > ratio * wants)
       return false;
     ++visits;
+    if (part) {
+      DIAG(3);
+    }
     const vf4 q0 = nodes[2 * node];
     const vf4 q1 = nodes[2 * node + 1];
     const float tx0 = __builtin_fmaf(q0.x, inv.x, -oi.x), tx1 = __builtin_fmaf(q1.x, inv.x, -oi.x);
@@ -428,6 +497,9 @@ __device__ __forceinline__ bool bvh_hit_packet(const TraceParams &p, bool part, 
         const unsigned first = link & VR_LEAF_FIRST_MASK;
         const unsigned cnt = (link >> 27) & 15u;
         for (unsigned i = 0; i < cnt; ++i) {
+          if (part) {
+            DIAG(4);
+          }
           const unsigned q = first + i;
           float t;
           if (GEO == 0) {

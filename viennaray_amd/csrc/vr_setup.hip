@@ -12,8 +12,10 @@
 //                       ballot-based stable ranking (no LDS scatter buffers)
 //   karras_kernel       binary radix tree over the sorted codes (Karras 2012)
 //   fit_kernel          bottom-up AABB fit with arrival counters
-//   finalize_kernel     traversal nodes {lo,link}{hi,escape}: ranges of <= 4
-//                       primitives collapse into leaves, escape links by parent walk
+//   fit_kernel          ... + emitted subtree sizes and the source-side-first child order
+//   finalize_kernel     traversal nodes {lo,link}{hi,escape} in pre-order: ranges of
+//                       <= leafMax primitives collapse into leaves
+//   quantize_nodes      16-byte nodes (16-bit conservative boxes) for per-lane traversal
 //   pack_*_kernel       primitive records in leaf order
 //   nb_count / nb_fill  neighbourhood = stackless BVH range query around every
 //                       disc centre (per-axis |d| <= dist and |d|^2 <= dist^2,
@@ -249,7 +251,12 @@ __global__ void karras_kernel(SetupParams s) {
     s.parentInt[right] = (unsigned)i | 0x80000000u;
 }
 
-// bottom-up AABB fit: thread = sorted position; the second arriver at a node fits it
+// bottom-up AABB fit: thread = sorted position; the second arriver at a node fits it.
+// The same pass computes what the pre-order layout needs: the number of traversal
+// nodes each subtree EMITS (a range of <= leafMax primitives collapses into one leaf)
+// and which child the traversal should visit first (bit 31): the one whose box centre
+// lies closer to the source plane, so that primary rays meet their first hit early
+// and the escape-link walk culls everything behind it.
 __global__ void fit_kernel(SetupParams s) {
   const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= s.n || s.n < 2)
@@ -263,63 +270,151 @@ __global__ void fit_kernel(SetupParams s) {
     const float *a = (L & CHILD_LEAF) ? s.sbox + 6 * (size_t)(L & ~CHILD_LEAF) : s.nodeBox + 6 * (size_t)L;
     const float *b = (R & CHILD_LEAF) ? s.sbox + 6 * (size_t)(R & ~CHILD_LEAF) : s.nodeBox + 6 * (size_t)R;
     float *o = s.nodeBox + 6 * (size_t)p;
-    for (int k = 0; k < 3; ++k) {
-      o[k] = fminf(__hip_atomic_load(&a[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                   __hip_atomic_load(&b[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      o[3 + k] = fmaxf(__hip_atomic_load(&a[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                       __hip_atomic_load(&b[3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    float ba[6], bb[6];
+    for (int k = 0; k < 6; ++k) {
+      ba[k] = __hip_atomic_load(&a[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bb[k] = __hip_atomic_load(&b[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    for (int k = 0; k < 3; ++k) {
+      o[k] = fminf(ba[k], bb[k]);
+      o[3 + k] = fmaxf(ba[3 + k], bb[3 + k]);
+    }
+    const unsigned sl =
+        (L & CHILD_LEAF) ? 1u : (__hip_atomic_load(&s.subSize[L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7FFFFFFFu);
+    const unsigned sr =
+        (R & CHILD_LEAF) ? 1u : (__hip_atomic_load(&s.subSize[R], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x7FFFFFFFu);
+    const unsigned cnt = s.rangeHi[p] - s.rangeLo[p] + 1u;
+    const unsigned size = cnt <= s.leafMax ? 1u : 1u + sl + sr;
+    const int ax = s.orderAxis;
+    const bool rightFirst = s.orderSign * ((bb[ax] + bb[3 + ax]) - (ba[ax] + ba[3 + ax])) > 0.f;
+    s.subSize[p] = size | (rightFirst ? 0x80000000u : 0u);
     if (p == 0)
       return;
     p = s.parentInt[p] & 0x7FFFFFFFu;
   }
 }
 
-// node numbering of the traversal array: internal node i -> i, singleton leaf of
-// sorted position q -> (n - 1) + q
+// Traversal nodes, written twice from the (child-ordered, leaf-collapsed) tree:
+//  * s.nodes   : build numbering (internal i -> i, singleton leaf of sorted position q ->
+//                n-1+q): the two children of a node are NEIGHBOURS in memory, which is what
+//                the packet traversal's scalar fetches like (a missed first child is
+//                followed by its sibling, same 64-byte line).  Explicit link + escape.
+//  * s.nodesPre: PRE-ORDER: the first child of an internal node is the next node, the
+//                escape of any node is the node after its subtree.  Source of the 16-byte
+//                nodes of the per-lane walk, which keep ONE link word thanks to that.
+// Thread t = node of the build numbering; a node below a collapsed range is not emitted.
+// One walk to the root yields both the pre-order index (every ancestor contributes 1,
+// plus the size of the sibling subtree where the path is the second child) and the
+// escape in build numbering (sibling of the nearest ancestor-or-self that is a first
+// child).
+__device__ __forceinline__ unsigned sub_size(const SetupParams &s, unsigned child) {
+  return (child & CHILD_LEAF) ? 1u : (s.subSize[child] & 0x7FFFFFFFu);
+}
 __device__ __forceinline__ unsigned node_of_child(const SetupParams &s, unsigned c) {
   return (c & CHILD_LEAF) ? (s.n - 1u) + (c & ~CHILD_LEAF) : c;
-}
-
-// escape of a node = right sibling of the first ancestor-or-self that is a left child
-__device__ __forceinline__ unsigned escape_of(const SetupParams &s, unsigned parentWord) {
-  unsigned pw = parentWord; // parent index | right-child flag of the current node
-  for (;;) {
-    const unsigned p = pw & 0x7FFFFFFFu;
-    if (!(pw & 0x80000000u))
-      return node_of_child(s, s.childR[p]); // current node is the left child
-    if (p == 0)
-      return VR_END;
-    pw = s.parentInt[p];
-  }
 }
 
 __global__ void finalize_kernel(SetupParams s) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned n = s.n;
   float4 *nodes = reinterpret_cast<float4 *>(s.nodes);
+  float4 *nodesPre = reinterpret_cast<float4 *>(s.nodesPre);
   if (n == 1) {
     if (t == 0) {
       const float *b = s.sbox;
-      nodes[0] = make_float4(b[0], b[1], b[2], __uint_as_float(VR_LEAF | (1u << 27) | 0u));
-      nodes[1] = make_float4(b[3], b[4], b[5], __uint_as_float(VR_END));
+      const float4 a0 = make_float4(b[0], b[1], b[2], __uint_as_float(VR_LEAF | (1u << 27) | 0u));
+      const float4 a1 = make_float4(b[3], b[4], b[5], __uint_as_float(VR_END));
+      nodes[0] = nodesPre[0] = a0;
+      nodes[1] = nodesPre[1] = a1;
+      s.subSize[0] = 1u;
     }
     return;
   }
-  if (t < n - 1) { // internal node t
-    const unsigned lo = s.rangeLo[t], hi = s.rangeHi[t], cnt = hi - lo + 1;
-    const float *b = s.nodeBox + 6 * (size_t)t;
-    const unsigned link = cnt <= (unsigned)VR_LEAF_MAX ? (VR_LEAF | (cnt << 27) | lo) : node_of_child(s, s.childL[t]);
-    const unsigned esc = t == 0 ? VR_END : escape_of(s, s.parentInt[t]);
-    nodes[2 * (size_t)t] = make_float4(b[0], b[1], b[2], __uint_as_float(link));
-    nodes[2 * (size_t)t + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(esc));
-  } else if (t < 2 * n - 1) { // singleton leaf of sorted position q
-    const unsigned q = t - (n - 1);
-    const float *b = s.sbox + 6 * (size_t)q;
-    const unsigned esc = escape_of(s, s.parentLeaf[q]);
-    nodes[2 * (size_t)t] = make_float4(b[0], b[1], b[2], __uint_as_float(VR_LEAF | (1u << 27) | q));
-    nodes[2 * (size_t)t + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(esc));
+  if (t >= 2 * n - 1)
+    return;
+  const bool internal = t < n - 1;
+  const unsigned q = internal ? 0u : t - (n - 1);
+  unsigned pw = 0; // parent index | "I am the right child"
+  bool haveParent = true;
+  if (internal) {
+    if (t == 0)
+      haveParent = false;
+    else
+      pw = s.parentInt[t];
+  } else {
+    pw = s.parentLeaf[q];
   }
+  if (haveParent) { // not emitted below a collapsed range (ancestors' ranges only grow)
+    const unsigned pp = pw & 0x7FFFFFFFu;
+    if (s.rangeHi[pp] - s.rangeLo[pp] + 1u <= s.leafMax)
+      return;
+  }
+  unsigned pre = 0, escBuild = VR_END;
+  bool escFound = false;
+  while (haveParent) {
+    const unsigned pp = pw & 0x7FFFFFFFu;
+    const bool amRight = (pw & 0x80000000u) != 0u;
+    const bool rightFirst = (s.subSize[pp] & 0x80000000u) != 0u;
+    pre += 1u;
+    if (amRight != rightFirst) { // second child: the first child's subtree comes before
+      pre += sub_size(s, rightFirst ? s.childR[pp] : s.childL[pp]);
+    } else if (!escFound) {      // first child: the walk continues with the sibling
+      escBuild = node_of_child(s, rightFirst ? s.childL[pp] : s.childR[pp]);
+      escFound = true;
+    }
+    if (pp == 0)
+      break;
+    pw = s.parentInt[pp];
+  }
+  const unsigned total = s.subSize[0] & 0x7FFFFFFFu;
+  unsigned linkPre, linkBuild, mySize;
+  const float *b;
+  if (internal) {
+    const unsigned lo = s.rangeLo[t], cnt = s.rangeHi[t] - lo + 1u;
+    const unsigned w = s.subSize[t];
+    mySize = w & 0x7FFFFFFFu;
+    if (cnt <= s.leafMax) {
+      linkPre = linkBuild = VR_LEAF | (cnt << 27) | lo;
+    } else {
+      linkPre = pre + 1u;
+      linkBuild = node_of_child(s, (w & 0x80000000u) ? s.childR[t] : s.childL[t]);
+    }
+    b = s.nodeBox + 6 * (size_t)t;
+  } else {
+    mySize = 1u;
+    linkPre = linkBuild = VR_LEAF | (1u << 27) | q;
+    b = s.sbox + 6 * (size_t)q;
+  }
+  const unsigned escPre = pre + mySize >= total ? VR_END : pre + mySize;
+  nodes[2 * (size_t)t] = make_float4(b[0], b[1], b[2], __uint_as_float(linkBuild));
+  nodes[2 * (size_t)t + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(escBuild));
+  nodesPre[2 * (size_t)pre] = make_float4(b[0], b[1], b[2], __uint_as_float(linkPre));
+  nodesPre[2 * (size_t)pre + 1] = make_float4(b[3], b[4], b[5], __uint_as_float(escPre));
+}
+
+// 16-byte form of the same nodes for the per-lane traversal: the box on a 16-bit grid of
+// the scene (rounded outwards and widened by one cell, so the test stays conservative
+// under the float rounding of the quantised-space slab test) + ONE link word:
+//   internal: escape index (VR_QEND when none)        [first child = this + 1]
+//   leaf    : VR_LEAF | cnt << 27 | first primitive   [escape      = this + 1]
+__global__ void quantize_nodes_kernel(const float4 *nodes, unsigned numNodes, float bx, float by, float bz, float sx,
+                                      float sy, float sz, uint4 *qnodes) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numNodes)
+    return;
+  const float4 a = nodes[2 * (size_t)i], b = nodes[2 * (size_t)i + 1];
+  const float base[3] = {bx, by, bz}, sc[3] = {sx, sy, sz};
+  const float lo[3] = {a.x, a.y, a.z}, hi[3] = {b.x, b.y, b.z};
+  unsigned ql[3], qh[3];
+  for (int k = 0; k < 3; ++k) {
+    const float l = floorf((lo[k] - base[k]) * sc[k]) - 1.f;
+    const float h = ceilf((hi[k] - base[k]) * sc[k]) + 1.f;
+    ql[k] = (unsigned)fminf(fmaxf(l, 0.f), 65535.f);
+    qh[k] = (unsigned)fminf(fmaxf(h, 0.f), 65535.f);
+  }
+  const unsigned link = __float_as_uint(a.w), esc = __float_as_uint(b.w);
+  const unsigned w = (link & VR_LEAF) ? link : (esc == VR_END ? VR_QEND : esc);
+  qnodes[i] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), w);
 }
 
 // sorted boxes, leafOfOrig, primitive records in leaf order
@@ -449,6 +544,16 @@ hipError_t launch_setup_bvh(const SetupParams &sp, unsigned *scanTmp, hipStream_
     hipLaunchKernelGGL(fit_kernel, dim3(g256), dim3(256), 0, st, s);
   }
   hipLaunchKernelGGL(finalize_kernel, dim3((2 * n - 1 + 255) / 256), dim3(256), 0, st, s);
+  return hipGetLastError();
+}
+
+hipError_t launch_quantize_nodes(const float *nodes, unsigned numNodes, const float *base3, const float *scale3,
+                                 uint32_t *qnodes, hipStream_t st) {
+  if (numNodes == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(quantize_nodes_kernel, dim3((numNodes + 255) / 256), dim3(256), 0, st,
+                     reinterpret_cast<const float4 *>(nodes), numNodes, base3[0], base3[1], base3[2], scale3[0],
+                     scale3[1], scale3[2], reinterpret_cast<uint4 *>(qnodes));
   return hipGetLastError();
 }
 

@@ -245,10 +245,11 @@ __global__ __launch_bounds__(VR_BLOCK) void scan_add_kernel(unsigned *data, unsi
 // ---------------------------------------------------------------------------
 // reflection sampling (rayUtil.hpp:266-283 + rayReflection.hpp:31-50)
 // ---------------------------------------------------------------------------
-template <int D> __device__ __forceinline__ V3 reflect_diffuse(const V3 &n, Rng &rng, unsigned &t2) {
+template <int D> __device__ __forceinline__ V3 reflect_diffuse(const V3 &n, Rng &rng, unsigned &t2 VR_DIAG_ARGS) {
   float x, y;
   double x2py2;
   do {
+    DIAG(7);
     x = canon_f32(rng_next(rng, t2)) * 2.0f + -1.0f;
     y = canon_f32(rng_next(rng, t2)) * 2.0f + -1.0f;
     x2py2 = (double)(x * x + y * y);
@@ -304,7 +305,13 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
 // (SGPR budget: 256-thread blocks per CU = min(8, 800 / (ceil(sgpr/16)*16 + 16)) on gfx950,
 //  MI355X_MICROARCH.md; 80 keeps 8 blocks resident)
 template <int D, int GEO, int PARTICLE, bool ABSORB>
-__global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void trace_kernel(const TraceParams p) {
+__global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
+__attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_kernel(const TraceParams p) {
+  // CARRY: lanes whose BVH walk is still under way when most of the wave is done keep
+  // their cursor over the state-machine / refill phase (see the round structure below).
+  // The absorbing kernel does without: its rounds are packets or short walks, and the
+  // extra live registers would cost it the 8th wave per SIMD.
+  constexpr bool CARRY = !ABSORB;
   __shared__ float wallS[96];
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
@@ -325,6 +332,13 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
   unsigned numReflections = 0, boundaryHits = 0;
   bool hitFromBack = false;
   bool fresh = false; // first segment of a ray pulled from the sorted stream
+  bool start = false; // this lane begins a new trace segment in this round
+  unsigned node = VR_END; // cursor of the lane's BVH walk (< numNodes while under way)
+  HitRec h;               // closest hit so far of the lane's current segment
+  h.t = 0.f;
+  h.geom = -1;
+  h.prim = 0u;
+  h.pos = 0u;
   Rng rng;
   rng_resume(rng, 0u, 0u, 0ull, 0ull);
   rng.scratch = p.rngScratch + (size_t)gwave * (312u * 64u) + lane;
@@ -341,6 +355,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
   unsigned spanCounts = 0; // lane i: ray count of bin spanStart + i
   unsigned packetSkip = 0, packetFails = 0; // wave-uniform back-off of packet attempts
   bool exhausted = false;
+  VR_DIAG_DECL
 
   for (;;) {
     // keep the compiler from hoisting the (loop-invariant) LDS wall table into
@@ -385,6 +400,9 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
         continue;
       }
       ++rep;
+      if (!active) {
+        DIAG(8);
+      }
       const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
       const unsigned avail = curCnt - curOff;
       if (!active && rank < avail) {
@@ -401,6 +419,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
         hitFromBack = false;
         fresh = true;
         active = true;
+        start = true;
         if (!ABSORB) {
           const unsigned idxOff = __float_as_uint(b.z);
           const ulonglong2 cur = *reinterpret_cast<const ulonglong2 *>(rayAB + REC * (size_t)j + 2);
@@ -413,35 +432,58 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
     if (!__ballot(active))
       break;
 
-    // ---- closest hit of one trace segment (rtcIntersect1, rayTraceKernel.hpp:163-167) ----
-    // Rays that were just pulled from the sorted stream are coherent: they take the
-    // wave-uniform packet traversal.  Continuing rays (after a wall or a bounce)
-    // have scattered: per-lane traversal.
-    HitRec h;
-    hit_init_walls(p, wallS, org, dir, tnear, h); // (idle lanes compute on stale values; unused)
-    // Every iteration first tries the wave-uniform packet traversal for all active lanes
-    // with a bounded number of node visits: freshly sorted rays, and rays that left the
-    // same surface patch, finish well inside the budget; a scattered set of rays
-    // exhausts it and is finished lane by lane.
-    const bool usePacket = !(p.debugFlags & 32u) && packetSkip == 0 && __popcll(__ballot(active)) >= 8;
+    // ---- closest hit of a trace segment (rtcIntersect1, rayTraceKernel.hpp:163-167) ----
+    // A round: lanes that begin a segment test the walls; if the whole wave begins together
+    // (freshly sorted, coherent rays) it first tries the wave-uniform packet traversal with
+    // a bounded number of node visits; otherwise, and when the packet gives up, every lane
+    // walks its own path — but only until the number of lanes still walking drops below
+    // p.walkExit: the lanes that are done run the state machine and start their next
+    // segment (or pull a new ray) while the stragglers keep their cursor and closest hit
+    // for the next round, so one long walk does not idle the other 63 lanes.
+    if (active) {
+      DIAG(0);
+    }
+    if (start) {
+      DIAG(9);
+    }
+    {
+      HitRec hw;
+      hit_init_walls(p, wallS, org, dir, tnear, hw); // (non-starting lanes compute on stale values; unused)
+      if (!CARRY || start) { // (!CARRY: every active lane starts a segment in every round)
+        h = hw;
+        node = 0u;
+      }
+    }
+    const unsigned long long carried = CARRY ? __ballot(active && !start) : 0ull;
+    start = false;
+    const bool usePacket =
+        !(p.debugFlags & 32u) && carried == 0ull && packetSkip == 0 && __popcll(__ballot(active)) >= 8;
     bool packetDone = false;
     if (usePacket) {
-      packetDone = bvh_hit_packet<GEO>(p, active, org, dir, tnear, h, p.packetBudget, p.packetRatio);
+      packetDone = bvh_hit_packet<GEO>(p, active, org, dir, tnear, h, p.packetBudget, p.packetRatio VR_DIAG_PASS);
       // a wave whose rays have scattered stops paying for hopeless packets for a while
       packetFails = packetDone ? 0u : (packetFails < 6u ? packetFails + 1u : 6u);
       packetSkip = packetDone ? 0u : (1u << packetFails) - 1u;
+      if (packetDone)
+        node = VR_END;
     } else if (packetSkip) {
       --packetSkip;
     }
-    if (active && !packetDone)
-      bvh_hit_lane<GEO>(p, org, dir, tnear, h);
+    if (!packetDone) {
+      const unsigned walking = (unsigned)__popcll(__ballot(active && node < p.numNodes));
+      const unsigned minLanes = (!CARRY || exhausted || walking <= p.walkExit) ? 1u : p.walkExit;
+      bvh_walk_lanes<GEO>(p, active, org, dir, tnear, h, node, minLanes VR_DIAG_PASS);
+    }
+    const bool fin = active && node >= p.numNodes; // this lane's segment is resolved
     const bool wasFresh = fresh;
-    fresh = false;
+    if (fin)
+      fresh = false;
     // merge same-disk credits of the wave into one atomic when that is likely to pay: rays
     // of a packet (small scenes spread their credits over accumulator replicas instead)
     const bool aggregate = packetDone;
 
-    if (active) {
+    if (fin) {
+      DIAG(5);
       // ---- the reference's state machine for this segment (rayTraceKernel.hpp:169-335) ----
       ++cTraces;
       if (h.geom < 0) { // miss, :172-176
@@ -509,6 +551,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
             }
           } else {
             ++cGeo;
+            DIAG(11);
             const u64 wfx = weight_fx(rayWeight);
             // surfaceCollision, rayParticle.hpp:148-156
             if (!(p.debugFlags & 1u)) {
@@ -521,6 +564,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
               // every overlapping neighbour disk is credited the full weight (:271-300)
               const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
               for (unsigned j = nb; j < ne; ++j) {
+                DIAG(6);
                 const unsigned q = p.nbIds[j];
                 const float4 c4 = prims[2 * q];
                 const float4 n4 = prims[2 * q + 1];
@@ -544,7 +588,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
                 // surfaceReflection, rayParticle.hpp:137-146 / 178-187
                 V3 newDir;
                 if (PARTICLE == 0)
-                  newDir = reflect_diffuse<D>(geomNormal, rng, cTier2);
+                  newDir = reflect_diffuse<D>(geomNormal, rng, cTier2 VR_DIAG_PASS);
                 else
                   newDir = reflect_specular(rayDirection, geomNormal);
                 rayWeight = wAfter;
@@ -557,6 +601,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
                   const float renewWeight = (float)(0.3 * 1.0);
                   bool reflect = true;
                   if (!(rayWeight >= lowerThreshold)) {
+                    DIAG(10);
                     const double killProbability = 1.0 - (double)(rayWeight / renewWeight);
                     if (canon_f64(rng_next(rng, cTier2)) < killProbability)
                       reflect = false;
@@ -580,9 +625,19 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void
         cBoundary += boundaryHits;
         cRefl += numReflections;
       }
+      start = active; // still alive: the next segment begins in the next round
     }
   }
 
+#ifdef VR_DIAG
+  for (int k = 0; k < 12; ++k) {
+    const unsigned long long sw = wave_sum(diagW[k]), sl = wave_sum(diagL[k]);
+    if (lane == 0 && sl) {
+      atomicAdd(&p.counters[16 + 2 * k], sw);
+      atomicAdd(&p.counters[16 + 2 * k + 1], sl);
+    }
+  }
+#endif
   const unsigned vals[8] = {cTraces, cNongeo, cGeo, 0u, cBoundary, cRefl, cTerm, cTier2};
 #pragma unroll
   for (int i = 0; i < 8; ++i) {

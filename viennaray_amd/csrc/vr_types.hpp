@@ -14,6 +14,7 @@ constexpr uint32_t VR_LEAF = 0x80000000u;
 constexpr uint32_t VR_END = 0xFFFFFFFFu;
 constexpr uint32_t VR_LEAF_FIRST_MASK = (1u << 27) - 1;
 constexpr int VR_LEAF_MAX = 4;
+constexpr uint32_t VR_QEND = 0x7FFFFFFFu; // "no escape" in a 16-byte node (bit 31 is the leaf flag)
 
 // Primitive records, stored in BVH-leaf (Morton) order so a leaf is one
 // contiguous, coalescable run:
@@ -36,7 +37,10 @@ constexpr int VR_BLOCK = 256;
 
 struct TraceParams {
   // geometry (device pointers)
-  const float *nodes;         // float4 pairs
+  const float *nodes;         // float4 pairs (pre-order; packet traversal, scalar fetch)
+  const uint32_t *qnodes;     // uint4 per node: 16-bit boxes + link (per-lane traversal)
+  uint32_t numNodes;
+  float qbase[3], qscale[3];  // quantised coordinate = (x - qbase) * qscale
   const float *prims;         // float4 records
   const uint32_t *nbOff;      // [numPrims+1], disk neighbourhood CSR (leaf order)
   const uint32_t *nbIds;      // leaf positions
@@ -81,6 +85,8 @@ struct TraceParams {
   int32_t binT1, binT2;           // cells per axis
   int32_t binTiles;               // 8x8-cell tiles per row (3-D)
   uint32_t packetBudget;          // node visits a packet traversal may spend before giving up
+  uint32_t walkPark;              // per-lane walk: leaves are tested when this % of the lanes under way are parked
+  uint32_t walkExit;              // the per-lane walk of a round ends when fewer lanes than this are still walking
   uint32_t packetRatio;           // ... and it gives up when union visits > ratio x mean per-ray path
   uint32_t debugFlags;            // VR_DEBUG_FLAGS (timing experiments; 0 in production)
 };
@@ -96,6 +102,9 @@ struct SetupParams {
   uint32_t n;
   int32_t geo, D;
   float nbDist;
+  uint32_t leafMax;       // subtrees of <= leafMax primitives become one leaf (<= 15)
+  int32_t orderAxis;      // children are ordered along this axis ...
+  float orderSign;        // ... larger sign * coordinate (= nearer the source plane) first
   // work buffers
   float *box, *sbox;      // 6 per primitive: original order / sorted order
   uint32_t *bounds;       // 6 ordered-uint scene bounds
@@ -103,8 +112,10 @@ struct SetupParams {
   uint32_t *valsA, *valsB, *sortTable;
   uint32_t *rangeLo, *rangeHi, *childL, *childR, *parentInt, *parentLeaf, *arrive;
   float *nodeBox;         // 6 per internal node
+  uint32_t *subSize;      // per internal node: emitted subtree size | right-child-first << 31
   // outputs
-  float *nodes;           // (2n-1) x 8 floats
+  float *nodes;           // (2n-1) x 8 floats, build numbering (siblings adjacent)
+  float *nodesPre;        // the emitted nodes in pre-order (source of the 16-byte nodes)
   float *prims;
   uint32_t *leafOfOrig, *order;
   uint32_t *nbOff, *nbIds;
