@@ -1,8 +1,7 @@
 cd $GRAFT_REPO_ROOT
-for pk in 10 34 60 100; do
-for w in 1 32; do
-export VR_WALK_EXIT=$w VR_WALK_PARK=$pk
-echo "=== park $pk walkExit $w: trench3d 0.1"
-python3 tools_case_bench.py trench3d 0.1 4000 1 2>&1 | grep -E "walk steps|leaf prim|state mach|Mrays"
-done
-done
+echo "=== trench3d 0.1"
+python3 tools_case_bench.py trench3d 0.1 4000 1 2>&1 | tail -14
+echo "=== C2 0.1"
+python3 bench.py --cpu-rays 0 --sticking 0.1 --steps 1 --warmup 0 2>&1 | grep diag | tail -12
+echo "=== mesh 0.1"
+python3 tools_case_bench.py mesh 0.1 4000 1 2>&1 | tail -14

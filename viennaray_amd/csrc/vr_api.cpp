@@ -858,7 +858,7 @@ int vr_apply_prepare(vr_context *c) {
   p.walkPark = 34;
   if (const char *e = std::getenv("VR_WALK_PARK"))
     p.walkPark = (uint32_t)std::min(100, std::max(1, std::atoi(e)));
-  p.walkExit = 32;
+  p.walkExit = 24;
   if (const char *e = std::getenv("VR_WALK_EXIT"))
     p.walkExit = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   p.packetRatio = 3;

@@ -283,50 +283,64 @@ __device__ __forceinline__ bool wall_reachable(float W, float oa, float da) {
   return (c > 0.f && da > 0.f) || (c < 0.f && da < 0.f);
 }
 
-// boundary: 8 wall triangles {v0,e1,e2,Ng} in LDS; pairs (0,1) (2,3) lie on the
-// firstDir min/max planes, (4,5) (6,7) on the secondDir min/max planes
-__device__ __forceinline__ void hit_init_walls(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
-                                               const V3 &d, float tnear, HitRec &h) {
+__device__ __forceinline__ void hit_clear(HitRec &h) {
   h.t = 3.402823466e+38f;
   h.geom = -1;
   h.prim = 0xFFFFFFFFu;
   h.pos = 0;
-  if (!(p.debugFlags & 8u)) {
-    const float o1 = getc(o, p.firstDir), d1 = getc(d, p.firstDir);
-    const float o2 = getc(o, p.secondDir), d2 = getc(d, p.secondDir);
+}
+
+// boundary: 8 wall triangles {v0,e1,e2,Ng} in LDS; pairs (0,1) (2,3) lie on the
+// firstDir min/max planes, (4,5) (6,7) on the secondDir min/max planes.
+// Called AFTER the geometry walk with the geometry's closest hit in `h`: most rays meet
+// the surface long before they could reach a wall plane, and for those the (long)
+// triangle tests are skipped.  A wall wins against geometry at equal t (closest-hit rule:
+// boundary first); among walls the lower id wins.
+__device__ __forceinline__ void hit_walls(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
+                                          const V3 &d, float tnear, HitRec &h) {
+  if (p.debugFlags & 8u)
+    return;
+  HitRec hw;
+  hit_clear(hw);
+  const float tLimit = h.t * 1.001f; // (plane t below is approximate: generous margin; inf stays inf)
+  const float o1 = getc(o, p.firstDir), d1 = getc(d, p.firstDir);
+  const float o2 = getc(o, p.secondDir), d2 = getc(d, p.secondDir);
 #pragma unroll
-    for (int pair = 0; pair < 4; ++pair) {
-      const float *w0 = wallS + 24 * pair;
-      // the wall planes are the adjusted bbox faces: scalars, no LDS read needed to cull
-      const float W = pair == 0 ? p.lo1 : (pair == 1 ? p.hi1 : (pair == 2 ? p.lo2 : p.hi2));
-      const float oa = pair < 2 ? o1 : o2, da = pair < 2 ? d1 : d2;
-      if (!wall_reachable(W, oa, da))
+  for (int pair = 0; pair < 4; ++pair) {
+    const float *w0 = wallS + 24 * pair;
+    // the wall planes are the adjusted bbox faces: scalars, no LDS read needed to cull
+    const float W = pair == 0 ? p.lo1 : (pair == 1 ? p.hi1 : (pair == 2 ? p.lo2 : p.hi2));
+    const float oa = pair < 2 ? o1 : o2, da = pair < 2 ? d1 : d2;
+    if (!wall_reachable(W, oa, da))
+      continue;
+    {
+      // conservative pre-tests (the approximate reciprocal is fine, the margins are far
+      // above its rounding): the plane must come before the geometry hit, and where the
+      // ray meets it, it must lie inside the wall's extent along the tracing axis (the
+      // walls span the whole adjusted bbox there)
+      const float tw = (W - oa) * __builtin_amdgcn_rcpf(da);
+      if (tw > tLimit)
         continue;
-      {
-        // conservative rectangle pre-test: where the ray meets the wall plane it must lie
-        // inside the wall's extent along the tracing axis (the walls span the whole
-        // adjusted bbox there), up to a margin far above the rounding of either test
-        // (so the approximate reciprocal is fine)
-        const float tw = (W - oa) * __builtin_amdgcn_rcpf(da);
-        const float cr = getc(o, p.rayDir) + getc(d, p.rayDir) * tw;
-        if (cr < p.wallLoR || cr > p.wallHiR)
-          continue;
-      }
+      const float cr = getc(o, p.rayDir) + getc(d, p.rayDir) * tw;
+      if (cr < p.wallLoR || cr > p.wallHiR)
+        continue;
+    }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float *w = w0 + 12 * j;
-        float t;
-        if (hit_tri(o, d, tnear, mk(w[0], w[1], w[2]), mk(w[3], w[4], w[5]), mk(w[6], w[7], w[8]),
-                    mk(w[9], w[10], w[11]), t)) {
-          if (t < h.t) { // ascending wall id: ties keep the lower id
-            h.t = t;
-            h.geom = 0;
-            h.prim = (unsigned)(2 * pair + j);
-          }
+    for (int j = 0; j < 2; ++j) {
+      const float *w = w0 + 12 * j;
+      float t;
+      if (hit_tri(o, d, tnear, mk(w[0], w[1], w[2]), mk(w[3], w[4], w[5]), mk(w[6], w[7], w[8]),
+                  mk(w[9], w[10], w[11]), t)) {
+        if (t < hw.t) { // ascending wall id: ties keep the lower id
+          hw.t = t;
+          hw.geom = 0;
+          hw.prim = (unsigned)(2 * pair + j);
         }
       }
     }
   }
+  if (hw.geom == 0 && hw.t <= h.t)
+    h = hw;
 }
 
 __device__ __forceinline__ V3 safe_inverse(const V3 &d) {
@@ -528,8 +542,9 @@ __device__ __forceinline__ bool bvh_hit_packet(const TraceParams &p, bool part, 
 template <int GEO>
 __device__ __forceinline__ void closest_hit(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
                                             const V3 &d, float tnear, HitRec &h) {
-  hit_init_walls(p, wallS, o, d, tnear, h);
+  hit_clear(h);
   bvh_hit_lane<GEO>(p, o, d, tnear, h);
+  hit_walls(p, wallS, o, d, tnear, h);
 }
 
 // rayTraceKernel.hpp:462-507 (neighbour disk test)

@@ -433,7 +433,7 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
       break;
 
     // ---- closest hit of a trace segment (rtcIntersect1, rayTraceKernel.hpp:163-167) ----
-    // A round: lanes that begin a segment test the walls; if the whole wave begins together
+    // A round: if the whole wave begins a segment together
     // (freshly sorted, coherent rays) it first tries the wave-uniform packet traversal with
     // a bounded number of node visits; otherwise, and when the packet gives up, every lane
     // walks its own path — but only until the number of lanes still walking drops below
@@ -446,13 +446,9 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
     if (start) {
       DIAG(9);
     }
-    {
-      HitRec hw;
-      hit_init_walls(p, wallS, org, dir, tnear, hw); // (non-starting lanes compute on stale values; unused)
-      if (!CARRY || start) { // (!CARRY: every active lane starts a segment in every round)
-        h = hw;
-        node = 0u;
-      }
+    if (!CARRY || start) { // (!CARRY: every active lane starts a segment in every round)
+      hit_clear(h);
+      node = 0u;
     }
     const unsigned long long carried = CARRY ? __ballot(active && !start) : 0ull;
     start = false;
@@ -474,7 +470,9 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
       const unsigned minLanes = (!CARRY || exhausted || walking <= p.walkExit) ? 1u : p.walkExit;
       bvh_walk_lanes<GEO>(p, active, org, dir, tnear, h, node, minLanes VR_DIAG_PASS);
     }
-    const bool fin = active && node >= p.numNodes; // this lane's segment is resolved
+    const bool fin = active && node >= p.numNodes; // this lane's geometry walk is complete
+    if (fin)
+      hit_walls(p, wallS, org, dir, tnear, h); // boundary walls, where one can come before the hit
     const bool wasFresh = fresh;
     if (fin)
       fresh = false;
