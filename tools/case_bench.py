@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Times one apply() of a named fixture geometry on the GPU.
-usage: tools_case_bench.py <trench3d|trench2d|mesh|plane100> <sticking> <raysPerPoint> [repeat]"""
+usage: tools/case_bench.py <trench3d|trench2d|mesh|plane100> <sticking> <raysPerPoint> [repeat]"""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import viennaray_amd as vr
 from helpers import trench3d, trench2d, trench_mesh
 

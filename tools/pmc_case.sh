@@ -1,4 +1,4 @@
-# usage: tools_pmc_case.sh <tag> <program args...>   (PMC passes over one command, summary of trace/gen kernels)
+# usage: tools/pmc_case.sh <tag> <program args...>   (PMC passes over one command, summary of trace/gen kernels)
 cd /tmp && export TMPDIR=/tmp
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise a tools_profile.sh output directory: per-kernel stats and PMC sums
+"""Summarise a tools/profile.sh output directory: per-kernel stats and PMC sums
 per dispatch of the trace kernel (counter values are summed over the rows
 rocprofv3 emits per dispatch/dimension)."""
 import csv

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles bench.py on the GPU box: kernel trace + stats, then PMC passes (separate runs).
-# usage: tools_profile.sh <tag> [bench args...]
+# usage: tools/profile.sh <tag> [bench args...]
 set -o pipefail
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -16,5 +16,5 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_ATOMIC_su
   echo "pmc $C rc=$?"
 done
 # summaries
-python3 $R/tools_prof_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 $R/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
