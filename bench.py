@@ -172,7 +172,7 @@ def main():
                        "parallelism": f"ray-range shards x{world}, BVH replicated, int64 flux all-reduce"},
             "device_pipeline_ms": round(kavg, 4), "trace_kernel_ms": round(tavg, 4),
             "segments_per_step": int(np.mean(segs)), "Msegments_per_s": round(np.mean(segs) / (kavg * 1e-3) / 1e6, 2),
-            "trace_launches_per_step": 1 + int(math.ceil(max(args.rays - 65536, 0) / float(1 << 27))),  # probe + main batches
+            "trace_launches_per_step": int(math.ceil(args.rays / float(1 << 27))),  # one per batch of <= 2^27 rays
             "prepare_s": round(build_s, 4),
             "roofline": {"kernel": "trace_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

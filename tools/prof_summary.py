@@ -26,8 +26,8 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.cs
 
 # traffic of the dominant kernel per launch (MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 64-B
 # requests of 128-B wide reads as 64 B -> doubled; WRITE_SIZE exact), KB -> bytes.
-# A step launches trace_kernel twice: the 65536-ray probe and the main batch; "per launch" is the
-# mean over the MAIN launches (those above 10 % of the largest), the probe's share is < 0.1 %.
+# "per launch" = mean over the launches above 10 % of the largest (a step is one launch per
+# batch of <= 2^27 rays; the filter only matters for odd-sized last batches).
 import json
 vals = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -109,6 +109,7 @@ struct vr_context {
   DevBuf<float> dNodesPre;
   uint32_t numNodes = 0;         // traversal nodes emitted by the builder
   float qbase[3] = {0, 0, 0}, qscale[3] = {0, 0, 0}; // frame of the 16-byte nodes
+  float keyCoord = 0.f;          // sort plane of the ray stream on the tracing axis (host_sort_plane)
   int builtOrderAxis = -1;       // child order of the resident BVH (source side first)
   float builtOrderSign = 0.f;
   DevBuf<unsigned long long> dKeysA, dKeysB;
@@ -118,7 +119,6 @@ struct vr_context {
   DevBuf<float> dSlotRec, dSlotRec2, dWalls;
   DevBuf<unsigned long long> dSlotTape, dSlotTape2;
   DevBuf<uint32_t> dBinCount, dBinCount2;
-  DevBuf<float> dProbe; // {sum, count} of first-hit coordinates of the probe batch
   size_t slotStride = 0;
   uint32_t raysPerBin = 32;
   std::vector<hipEvent_t> evSort, evTraced; // per batch: sorted stream ready / trace finished
@@ -215,7 +215,6 @@ void vr_destroy(vr_context *c) {
   c->dSlotTape2.release();
   c->dBinCount.release();
   c->dBinCount2.release();
-  c->dProbe.release();
   c->dScanTmp.release();
   for (auto e : c->evK)
     (void)hipEventDestroy(e);
@@ -674,6 +673,7 @@ int vr_apply_prepare(vr_context *c) {
     // SourceRandom::getSourceArea (raySourceRandom.hpp:40-47)
     const int f = c->ts[1], s = c->ts[2];
     c->sourceArea = D == 2 ? (c->bbHi[f] - c->bbLo[f]) : (c->bbHi[f] - c->bbLo[f]) * (c->bbHi[s] - c->bbLo[s]);
+    c->keyCoord = host_sort_plane(c->geo, c->ts[0], c->ts[3] ? c->geo.minC[c->ts[0]] : c->geo.maxC[c->ts[0]]);
   }
 
   const uint32_t N = c->geo.numPrims;
@@ -763,7 +763,6 @@ int vr_apply_prepare(vr_context *c) {
     const size_t recFloats = c->absorb ? 8 : 12; // 32 B, or 32 B + the 16-B RNG cursors
     VR_HIP(c, c->dSlotRec.ensure(slots * recFloats));
     VR_HIP(c, c->dBinCount.ensure((size_t)nb + 1));
-    VR_HIP(c, c->dProbe.ensure(4));
     if (c->overlap) {
       VR_HIP(c, c->dSlotRec2.ensure(slots * recFloats));
       VR_HIP(c, c->dBinCount2.ensure((size_t)nb + 1));
@@ -807,8 +806,6 @@ int vr_apply_prepare(vr_context *c) {
   p.slotTape = c->absorb ? nullptr : c->dSlotTape.p;
   p.binCount = c->dBinCount.p;
   p.idxList = nullptr;
-  p.keyPlane = nullptr;
-  p.probeAcc = nullptr;
   p.batchFirst = first;
   p.batchCount = 0;
   p.slotStride = (uint32_t)c->slotStride;
@@ -847,9 +844,9 @@ int vr_apply_prepare(vr_context *c) {
     p.wallLoR = lr - margin;
     p.wallHiR = hr + margin;
   }
-  p.farCoord = c->ts[3] ? c->geo.minC[c->ts[0]] : c->geo.maxC[c->ts[0]];
+  p.keyCoord = c->keyCoord;
   if (const char *e = std::getenv("VR_KEY_COORD"))
-    p.farCoord = (float)std::atof(e);
+    p.keyCoord = (float)std::atof(e);
   p.invExt1 = (p.hi1 > p.lo1) ? 1.f / (p.hi1 - p.lo1) : 0.f;
   p.invExt2 = (p.hi2 > p.lo2) ? 1.f / (p.hi2 - p.lo2) : 0.f;
   p.packetBudget = 128;
@@ -904,7 +901,7 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   p.numBins = nbBatch;
   {
     // bins per queue grab: ~1024 rays for big batches, but never so many that a small
-    // batch (the probe) is handed to a few waves only
+    // batch (a short last one, a small launch) is handed to a few waves only
     const uint64_t waves = (uint64_t)c->grid * (VR_BLOCK / 64);
     p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, nbBatch / std::max<uint64_t>(waves * 2, 1)));
   }
@@ -962,29 +959,6 @@ int vr_apply_launch(vr_context *c) {
     VR_HIP(c, hipStreamWaitEvent(c->stream2, c->ev0, 0));
   c->numBatches = 0;
   uint64_t f = c->rayFirstLaunch;
-  // Probe batch: the first rays of a large launch are traced first (sorted on the far
-  // face of the geometry box) and report where their first segments end; the mean of
-  // that coordinate becomes the sort plane of the remaining batches, so the sort key
-  // predicts the first hit for any surface height, not just for flat geometry.
-  const uint64_t span = c->rayEndLaunch - c->rayFirstLaunch;
-  const uint32_t probeRays = 1u << 16;
-  bool probe = span >= 16ull * probeRays;
-  if (const char *e = std::getenv("VR_NO_PROBE"))
-    if (std::atoi(e))
-      probe = false;
-  c->params.keyPlane = nullptr;
-  c->params.probeAcc = nullptr;
-  if (probe) {
-    VR_HIP(c, hipMemsetAsync(c->dProbe.p, 0, 16, c->stream));
-    c->params.probeAcc = c->dProbe.p;
-    int r = run_batch(c, f, probeRays, c->numBatches);
-    c->params.probeAcc = nullptr;
-    if (r != VR_OK)
-      return r;
-    ++c->numBatches;
-    f += probeRays;
-    c->params.keyPlane = c->dProbe.p;
-  }
   for (; f < c->rayEndLaunch; f += c->batchCap) {
     const uint32_t cnt = (uint32_t)std::min<uint64_t>(c->batchCap, c->rayEndLaunch - f);
     int r = run_batch(c, f, cnt, c->numBatches);

@@ -412,6 +412,43 @@ void host_disk_areas(const HostGeometry &g, const int *bc2, int firstDir, int se
   }
 }
 
+float host_sort_plane(const HostGeometry &g, int axis, float fallback) {
+  const float lo = g.minC[axis], hi = g.maxC[axis];
+  if (g.numPrims == 0 || !(hi > lo))
+    return g.numPrims ? lo : fallback;
+  constexpr int SL = 256;
+  std::vector<double> w(SL, 0.0), wh(SL, 0.0);
+  const double inv = SL / ((double)hi - (double)lo);
+  for (uint32_t i = 0; i < g.numPrims; ++i) {
+    double h, a;
+    if (g.geo == 0) {
+      const float *d = &g.disk4[4 * (size_t)i];
+      const float *n = &g.normal3[3 * (size_t)i];
+      const double nn = std::sqrt((double)n[0] * n[0] + (double)n[1] * n[1] + (double)n[2] * n[2]);
+      h = d[axis];
+      a = nn > 0. ? (double)d[3] * d[3] * std::fabs((double)n[axis]) / nn : 0.;
+    } else {
+      const float *v0 = &g.verts[3 * (size_t)g.tris[3 * (size_t)i]];
+      const float *v1 = &g.verts[3 * (size_t)g.tris[3 * (size_t)i + 1]];
+      const float *v2 = &g.verts[3 * (size_t)g.tris[3 * (size_t)i + 2]];
+      const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+      const double e1[2] = {(double)v1[a1] - v0[a1], (double)v1[a2] - v0[a2]};
+      const double e2[2] = {(double)v2[a1] - v0[a1], (double)v2[a2] - v0[a2]};
+      h = ((double)v0[axis] + v1[axis] + v2[axis]) / 3.;
+      a = 0.5 * std::fabs(e1[0] * e2[1] - e1[1] * e2[0]); // area of the projection along the axis
+    }
+    int k = (int)((h - lo) * inv);
+    k = k < 0 ? 0 : (k >= SL ? SL - 1 : k);
+    w[k] += a;
+    wh[k] += a * h;
+  }
+  int best = 0;
+  for (int k = 1; k < SL; ++k)
+    if (w[k] > w[best])
+      best = k;
+  return w[best] > 0. ? (float)(wh[best] / w[best]) : fallback;
+}
+
 // ---------------------------------------------------------------------------
 // LBVH (host): 63-bit Morton codes of box centres, sort, split at the highest
 // differing bit, leaves of <= VR_LEAF_MAX primitives, nodes emitted in

@@ -100,14 +100,8 @@ __device__ __forceinline__ float fold_unit(float u, int bc) {
 }
 
 template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p, const V3 &org, const V3 &dir) {
-  // sort plane: the mean first-hit coordinate measured by the probe batch of this launch
-  // (the far face of the geometry box until that is known)
-  float keyCoord = p.farCoord;
-  if (p.keyPlane) {
-    const float cnt = p.keyPlane[1];
-    if (cnt > 0.f)
-      keyCoord = p.keyPlane[0] / cnt;
-  }
+  // sort plane: the coordinate on the tracing axis where most first hits are expected
+  const float keyCoord = p.keyCoord;
   const float dr = getc(dir, p.rayDir);
   float t = (keyCoord - p.srcCoord) / (fabsf(dr) > 1e-6f ? dr : copysignf(1e-6f, dr == 0.f ? -p.posNeg : dr));
   t = (p.debugFlags & 2u) ? 0.f : (t > 0.f ? t : 0.f); // flag 2: key on the origin instead
@@ -331,7 +325,6 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
   float rayWeight = 0.f;
   unsigned numReflections = 0, boundaryHits = 0;
   bool hitFromBack = false;
-  bool fresh = false; // first segment of a ray pulled from the sorted stream
   bool start = false; // this lane begins a new trace segment in this round
   unsigned node = VR_END; // cursor of the lane's BVH walk (< numNodes while under way)
   HitRec h;               // closest hit so far of the lane's current segment
@@ -417,7 +410,6 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
         numReflections = 0;
         boundaryHits = 0;
         hitFromBack = false;
-        fresh = true;
         active = true;
         start = true;
         if (!ABSORB) {
@@ -473,9 +465,6 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
     const bool fin = active && node >= p.numNodes; // this lane's geometry walk is complete
     if (fin)
       hit_walls(p, wallS, org, dir, tnear, h); // boundary walls, where one can come before the hit
-    const bool wasFresh = fresh;
-    if (fin)
-      fresh = false;
     // merge same-disk credits of the wave into one atomic when that is likely to pay: rays
     // of a packet (small scenes spread their credits over accumulator replicas instead)
     const bool aggregate = packetDone;
@@ -533,10 +522,6 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
             geomNormal = mk(n4.x, n4.y, n4.z);
           } else {
             geomNormal = mk(prims[4 * h.pos + 1].w, prims[4 * h.pos + 2].w, prims[4 * h.pos + 3].w);
-          }
-          if (p.probeAcc && wasFresh) { // probe launch: where do first segments end?
-            atomicAdd(&p.probeAcc[0], getc(hitPoint, p.rayDir));
-            atomicAdd(&p.probeAcc[1], 1.f);
           }
           const bool backfaceHit = vdot(rayDirection, geomNormal) > 0.f; // :224
           if (backfaceHit) {

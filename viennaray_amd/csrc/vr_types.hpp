@@ -78,9 +78,7 @@ struct TraceParams {
   float lo1, hi1, lo2, hi2;       // extents along firstDir / secondDir
   float wallLoR, wallHiR;         // wall extent along rayDir, widened by a safety margin
   // sort-key binning (far-plane crossing cell)
-  float farCoord;                 // geometry bbox face opposite the source, on rayDir
-  const float *keyPlane;          // device: {sum, count} of probe first-hit coordinates -> sort plane (or nullptr)
-  float *probeAcc;                // device: where a probe launch accumulates {sum, count} (or nullptr)
+  float keyCoord;                 // sort plane on rayDir: where most first hits are expected (host_sort_plane)
   float invExt1, invExt2;         // 1 / (hi - lo) along firstDir / secondDir (0 if degenerate)
   int32_t binT1, binT2;           // cells per axis
   int32_t binTiles;               // 8x8-cell tiles per row (3-D)
