@@ -428,3 +428,60 @@ def test_host_and_device_builders_agree(monkeypatch):
     fh, ih, sh = run()
     assert (fd == fh).all() and idv == ih
     assert sh["maxDepth"] > 0 and 0 < sd["nodes"] <= 2 * len(p) - 1
+
+
+SCHEDULING_KNOBS = [
+    {"VR_BATCH_RAYS": "40000"},                       # many batches
+    {"VR_BIN_CAP": "8", "VR_RAYS_PER_BIN": "16"},     # most rays overflow their bin
+    {"VR_RAYS_PER_BIN": "2"},                         # nearly empty bins
+    {"VR_WALK_EXIT": "1"}, {"VR_WALK_EXIT": "64"},    # no / eager straggler carry-over
+    {"VR_WALK_PARK": "1"}, {"VR_WALK_PARK": "100"},   # leaf batching extremes
+    {"VR_PACKET_BUDGET": "0"}, {"VR_PACKET_BUDGET": "100000", "VR_PACKET_RATIO": "1000"},
+    {"VR_DEBUG_FLAGS": "32"},                         # no packets at all
+    {"VR_LEAF_MAX": "1"}, {"VR_LEAF_MAX": "12"},
+    {"VR_ACC_REPLICAS": "1"}, {"VR_ACC_REPLICAS": "64"},
+    {"VR_NO_CHILD_ORDER": "1"},
+    {"VR_TRACE_BLOCKS": "1"},
+    {"VR_KEY_COORD": "-7.5"},
+]
+
+
+@pytest.mark.parametrize("geom", ["trench3d", "mesh", "trench2d"])
+def test_scheduling_knobs_do_not_change_results(geom, monkeypatch):
+    """Ray order, batching, bin geometry, packet / per-lane traversal policy, BVH leaf size and
+    child order, accumulator replication: none of it may change a single accumulator bit or
+    counter (int64 fixed-point sums + the order-independent closest-hit rule)."""
+    def run():
+        if geom == "mesh":
+            gd, v, tri = trench_mesh()
+            t = vr.TraceTriangle(3)
+            t.setGeometry(v, tri, gd)
+            t.setBoundaryConditions([BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY, BC.REFLECTIVE_BOUNDARY])
+            t.setNumberOfRaysPerPoint(12)
+        elif geom == "trench2d":
+            gd, p, n = trench2d()
+            t = vr.TraceDisk(2)
+            t.setGeometry(p, n, gd)
+            t.setSourceDirection(TD.POS_Y)
+            t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 2)
+            t.setNumberOfRaysPerPoint(1500)
+        else:
+            gd, p, n = trench3d()
+            t = vr.TraceDisk(3)
+            t.setGeometry(p, n, gd)
+            t.setBoundaryConditions([BC.REFLECTIVE_BOUNDARY, BC.PERIODIC_BOUNDARY, BC.PERIODIC_BOUNDARY])
+            t.setNumberOfRaysPerPoint(12)
+        t.setParticleType(vr.DiffuseParticle(0.15, "flux"))
+        t.setRngSeed(99)
+        t.apply()
+        return t.getFluxF64(), info_dict(t)
+
+    f0, i0 = run()
+    assert i0["reflections"] > 0 and i0["boundaryHits"] > 0
+    for knobs in SCHEDULING_KNOBS:
+        with monkeypatch.context() as m:
+            for k, v in knobs.items():
+                m.setenv(k, v)
+            f, i = run()
+        assert i == i0, knobs
+        assert (f == f0).all(), knobs
