@@ -63,6 +63,8 @@ typedef struct vr_trace_info {
   double timeTraceKernel; /* seconds: the trace kernel(s) alone (HIP events)        */
   int32_t warning;
   int32_t error;
+  uint64_t rngFullStates; /* diagnostic: rays that drew more than 156 numbers and continued
+                             on the full 312-word engine state       */
 } vr_trace_info;
 
 /* gpu::Particle-style POD (rayParticle.hpp:208-218): a built-in particle.

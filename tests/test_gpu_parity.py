@@ -485,3 +485,87 @@ def test_scheduling_knobs_do_not_change_results(geom, monkeypatch):
             f, i = run()
         assert i == i0, knobs
         assert (f == f0).all(), knobs
+
+
+# ---------------------------------------------------------------------------
+# edge cases of the reference's loop (limits, degenerate scenes, tiny launches)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("max_refl,max_bh", [(2, 1000), (1000000, 1), (0, 0)])
+def test_reflection_and_boundary_hit_limits(max_refl, max_bh):
+    """rayTraceKernel.hpp:206-214 / :320-324: rays stop at maxBoundaryHits / maxReflections"""
+    gd, p, n = trench3d()
+    t, o = make_pair_disks(p, n, gd, 3, [BC.REFLECTIVE_BOUNDARY] * 3, TD.POS_Z, ("diffuse", 0.05, 1), rays_pp=8)
+    t.setMaxReflections(max_refl)
+    o.set_max_reflections(max_refl)
+    t.setMaxBoundaryHits(max_bh)
+    o.set_max_boundary_hits(max_bh)
+    err, gi = compare(t, o, counter_slack=0)
+    assert gi["raysTerminated"] > 0
+
+
+@pytest.mark.parametrize("bcs", [[BC.REFLECTIVE_BOUNDARY, BC.IGNORE_BOUNDARY, BC.PERIODIC_BOUNDARY],
+                                 [BC.IGNORE_BOUNDARY, BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY]])
+def test_mixed_boundary_conditions(bcs):
+    """rayBoundary.hpp:23-25: the condition is picked by AXIS (Q13)"""
+    gd, p, n = trench3d()
+    t, o = make_pair_disks(p, n, gd, 3, bcs, TD.POS_Z, ("diffuse", 0.2, 1), rays_pp=10)
+    compare(t, o, counter_slack=0)
+
+
+def test_source_below_hits_back_faces():
+    """NEG_Z on the trench: every first hit is a back face (pass-through once, then kill, :224-249)"""
+    gd, p, n = trench3d()
+    t, o = make_pair_disks(p, n, gd, 3, [BC.PERIODIC_BOUNDARY] * 3, TD.NEG_Z, ("diffuse", 0.5, 1), rays_pp=5)
+    err, gi = compare(t, o, counter_slack=0)
+    assert gi["raysTerminated"] > 0
+
+
+@pytest.mark.parametrize("npts", [1, 2, 5])
+def test_degenerate_scenes(npts):
+    """one disk; coincident disks (equal Morton codes, equal t: lower id wins); a short row"""
+    if npts == 2:
+        pts = np.zeros((2, 3), np.float32)
+    else:
+        pts = np.stack([np.arange(npts, dtype=np.float32), np.zeros(npts, np.float32), np.zeros(npts, np.float32)], 1)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (npts, 1))
+    t, o = make_pair_disks(pts, nrm, 1.0, 3, [BC.REFLECTIVE_BOUNDARY] * 3, TD.POS_Z, ("diffuse", 0.3, 1),
+                           rays_fixed=5000)
+    t.apply()
+    o.apply(1)
+    assert info_dict(t) == {k: o.info()[k] for k in INFO_KEYS}
+    f, r = t.getLocalData().getVectorData(0), o.flux()
+    assert l2_rel(f, r) <= 5e-6
+    # a bounding box without extent makes the reference's disk-area code return NaN (0/0 normal,
+    # rayDiskBoundingBoxIntersector.hpp:124-135): same NaNs, same finite values
+    fn, rn = t.normalizeFlux(f), o.normalize_flux(r)
+    assert (np.isnan(fn) == np.isnan(rn)).all()
+    ok = ~np.isnan(rn)
+    assert l2_rel(fn[ok], rn[ok]) <= FLUX_TOL
+
+
+@pytest.mark.parametrize("rays", [1, 63, 65, 4097])
+def test_tiny_launches(rays):
+    pts, nrm = vr.io.plane_grid(12, 1.0)
+    t, o = make_pair_disks(pts, nrm, 1.0, 3, [BC.PERIODIC_BOUNDARY] * 3, TD.POS_Z, ("diffuse", 0.4, 1),
+                           rays_fixed=rays)
+    t.apply()
+    o.apply(1)
+    assert info_dict(t) == {k: o.info()[k] for k in INFO_KEYS}
+    assert l2_rel(t.getLocalData().getVectorData(0), o.flux()) <= 5e-6
+
+
+def test_long_bounce_chains_use_the_full_engine_state():
+    """A closed cavity (two facing planes, reflective side walls), sticking 0.02: a ray enters
+    through the back of the upper plane (first back hit passes, rayTraceKernel.hpp:235-240) and
+    bounces ~100 times until the roulette ends it, i.e. it draws far more than 156 numbers and
+    leaves the streaming tier for the 312-word state (tier 2) — the stream must stay exact."""
+    lo_p, lo_n = vr.io.plane_grid(12, 1.0)
+    hi_p = lo_p.copy()
+    hi_p[:, 2] = 3.0
+    hi_n = -lo_n
+    pts, nrm = np.concatenate([lo_p, hi_p]), np.concatenate([lo_n, hi_n])
+    t, o = make_pair_disks(pts, nrm, 1.0, 3, [BC.REFLECTIVE_BOUNDARY] * 3, TD.POS_Z, ("diffuse", 0.02, 1),
+                           rays_fixed=3000)
+    err, gi = compare(t, o, counter_slack=0)
+    assert gi["reflections"] > 50 * gi["numRays"]
+    assert t.getRayTraceInfo().rngFullStates > 1000  # the tier was really exercised

@@ -25,7 +25,7 @@ class TraceInfoPOD(C.Structure):
                 ("reflections", C.c_uint64), ("raysTerminated", C.c_uint64),
                 ("time", C.c_double), ("timeBuild", C.c_double), ("timeTrace", C.c_double),
                 ("timeTraceKernel", C.c_double),
-                ("warning", C.c_int32), ("error", C.c_int32)]
+                ("warning", C.c_int32), ("error", C.c_int32), ("rngFullStates", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

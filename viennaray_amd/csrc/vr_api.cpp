@@ -1005,6 +1005,7 @@ int vr_apply_finish(vr_context *c) {
   i.boundaryHits = cnt[C_BOUNDARY];
   i.reflections = cnt[C_REFLECTIONS];
   i.raysTerminated = cnt[C_TERMINATED];
+  i.rngFullStates = cnt[C_TIER2];
   i.timeTrace = ms * 1e-3;
   double kms = 0.0;
   for (size_t b = 0; b < c->numBatches; ++b) {
@@ -1081,6 +1082,7 @@ int vr_add_trace_info(vr_context *c, const vr_trace_info *o) {
   i.boundaryHits += o->boundaryHits;
   i.reflections += o->reflections;
   i.raysTerminated += o->raysTerminated;
+  i.rngFullStates += o->rngFullStates;
   return VR_OK;
 }
 

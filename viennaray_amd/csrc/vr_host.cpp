@@ -349,6 +349,13 @@ float disk_area_inside_xy(const float *disk, const float *nrm, float lx, float l
     const F3 ip{px, py, (dn.x * c.x + dn.y * c.y + dn.z * c.z - dn.x * px - dn.y * py) / dn.z};
     if (norm3(sub3(c, ip)) >= radius)
       continue;
+    // The reference derives each wall's normal from a triangle spanning the wall
+    // (rayDiskBoundingBoxIntersector.hpp:124-135); on a bounding box without extent along the
+    // wall that triangle is degenerate, its normalised normal is 0/0 and the area comes out
+    // NaN (single disk, one row of disks).  Reproduced rather than "fixed".
+    auto flat = [&](const Wall2D &w) { return w.axis == 0 ? hy == ly : hx == lx; };
+    if (flat(walls[k]) || flat(walls[k2]))
+      return std::numeric_limits<float>::quiet_NaN();
     auto circ = [&](const F3 &iDir, float d) {
       const float ca = dot3(sub3(c, ip), iDir);
       const F3 cp{ip.x + ca * iDir.x, ip.y + ca * iDir.y, ip.z + ca * iDir.z};
