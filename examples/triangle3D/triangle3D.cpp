@@ -38,5 +38,9 @@ int main(int argc, char **argv) {
   std::cout << "rays " << info.numRays << " geometryHits " << info.geometryHits << "\n";
   auto &localData = tracer.getLocalData();
   tracer.normalizeFlux(localData.getVectorData(0), NormalizationType::SOURCE);
+  double s = 0;
+  for (auto v : localData.getVectorData(0))
+    s += v;
+  std::cout << "mean normalised flux " << s / localData.getVectorData(0).size() << "\n";
   return 0;
 }

@@ -9,7 +9,8 @@
 //   viennaray::TracingData                         (rayTracingData.hpp:16-219)
 //   viennaray::TraceInfo, BoundaryCondition, TraceDirection, NormalizationType
 //   viennaray::DiskMesh / TriangleMesh             (rayMesh.hpp:82-131)
-//   rayInternal::readGridFromFile / readMeshFromFile / createPlaneGrid / writeVTK
+//   rayInternal::readGridFromFile / readMeshFromFile / createPlaneGrid / writeVTK / writeVTP
+//   LineMesh + convertLinesToTriangles (rayMesh.hpp)
 // so a reference example builds by pointing its include path here (see
 // examples/ and INTEGRATION.md).  The device computes in float; NumericType
 // double is accepted and converted at the boundary, as the reference does when
@@ -91,6 +92,44 @@ struct TriangleMesh {
   std::vector<Vec3D<unsigned>> triangles;
   float gridDelta = 0.f;
 };
+
+// rayMesh.hpp:27-80: 2-D surface as line segments; zero-length segments are dropped
+struct LineMesh {
+  LineMesh() = default;
+  LineMesh(const std::vector<Vec3Df> &pts, const std::vector<Vec2D<unsigned>> &lns, float delta)
+      : nodes(pts), gridDelta(delta) {
+    for (auto const &l : lns) {
+      const auto &p0 = nodes[l[0]];
+      const auto &p1 = nodes[l[1]];
+      const float dx = p1[0] - p0[0], dy = p1[1] - p0[1], dz = p1[2] - p0[2];
+      if (std::sqrt(dx * dx + dy * dy + dz * dz) > 1e-6f)
+        lines.push_back(l);
+    }
+  }
+  std::vector<Vec3Df> nodes;
+  std::vector<Vec2D<unsigned>> lines;
+  float gridDelta = 0.f;
+};
+
+// rayMesh.hpp:133-175: every line becomes a strip of two triangles of height gridDelta
+// (z = +-gridDelta/2); node 2i is node i at +z, node 2i+1 at -z
+inline TriangleMesh convertLinesToTriangles(const LineMesh &lineMesh) {
+  TriangleMesh mesh;
+  mesh.gridDelta = lineMesh.gridDelta;
+  const float w2 = lineMesh.gridDelta * 0.5f;
+  mesh.nodes.reserve(lineMesh.nodes.size() * 2);
+  for (auto const &p : lineMesh.nodes) {
+    mesh.nodes.push_back(Vec3Df{p[0], p[1], w2});
+    mesh.nodes.push_back(Vec3Df{p[0], p[1], -w2});
+  }
+  mesh.triangles.reserve(lineMesh.lines.size() * 2);
+  for (auto const &line : lineMesh.lines) {
+    const unsigned p0 = line[0] * 2, p1 = line[1] * 2;
+    mesh.triangles.push_back(Vec3D<unsigned>{p0, p1, p0 + 1});
+    mesh.triangles.push_back(Vec3D<unsigned>{p0 + 1, p1, p1 + 1});
+  }
+  return mesh;
+}
 
 // ---- TracingData (vector data part) ------------------------------------------------
 template <typename NumericType> class TracingData {
@@ -373,6 +412,11 @@ public:
       pts[i] = {(NumericType)mesh.nodes[i][0], (NumericType)mesh.nodes[i][1], (NumericType)mesh.nodes[i][2]};
     setGeometry(pts, mesh.triangles, (NumericType)mesh.gridDelta);
   }
+  // rayTraceTriangle.hpp:76-81 (2-D only)
+  void setGeometry(const LineMesh &mesh) {
+    static_assert(D == 2 || D == 3, "dimension");
+    setGeometry(convertLinesToTriangles(mesh));
+  }
   template <typename T> void setMaterialIds(std::vector<T> const &materialIds) {
     std::vector<int32_t> ids(materialIds.begin(), materialIds.end());
     if (this->ctx_)
@@ -418,14 +462,15 @@ void readMeshFromFile(const std::string &fileName, NumericType &gridDelta, std::
   nodes.resize(nn);
   for (auto &p : nodes)
     f >> id >> p[0] >> p[1] >> p[2];
-  elements.clear();
-  elements.reserve(ne);
-  VectorType<unsigned, D> e;
-  while (elements.size() < ne && (f >> id)) {
+  // like the reference, a file holding fewer elements than declared leaves the rest
+  // value-initialised (lineMesh.dat: 130 declared, 129 present -> one zero-length line)
+  elements.assign(ne, VectorType<unsigned, D>{});
+  for (size_t i = 0; i < ne && (f >> id); ++i) {
+    VectorType<unsigned, D> e{};
     for (int j = 0; j < D; ++j)
       f >> e[j];
     if (f)
-      elements.push_back(e);
+      elements[i] = e;
   }
 }
 
@@ -462,5 +507,42 @@ void writeVTK(const std::string &filename, const std::vector<Vec3D<NumericType>>
   f << "CELL_DATA " << flux.size() << "\nSCALARS flux float\nLOOKUP_TABLE default\n";
   for (auto v : flux)
     f << v << "\n";
+}
+
+// rayUtil.hpp:451-555: VTK PolyData (lines for D == 2, polygons for D == 3) + cell data
+template <typename NumericType, int D = 3, typename ResultType = NumericType>
+void writeVTP(const std::string &filename, const std::vector<Vec3D<NumericType>> &points,
+              const std::vector<VectorType<unsigned, D>> &elements, const std::vector<ResultType> &flux) {
+  std::ofstream f(filename.c_str());
+  if (!f.is_open())
+    return;
+  f << "<?xml version=\"1.0\"?>\n<VTKFile type=\"PolyData\" version=\"0.1\" byte_order=\"LittleEndian\">\n  <PolyData>\n";
+  f << "    <Piece NumberOfPoints=\"" << points.size() << "\" NumberOfVerts=\"0\" NumberOfLines=\""
+    << (D == 2 ? elements.size() : 0) << "\" NumberOfStrips=\"0\" NumberOfPolys=\"" << (D == 2 ? 0 : elements.size())
+    << "\">\n      <Points>\n        <DataArray type=\"Float32\" NumberOfComponents=\"3\" format=\"ascii\">\n";
+  for (auto const &p : points)
+    f << (float)p[0] << " " << (float)p[1] << " " << (float)p[2] << "\n";
+  f << "        </DataArray>\n      </Points>\n      " << (D == 2 ? "<Lines>" : "<Polys>")
+    << "\n        <DataArray type=\"Int32\" Name=\"connectivity\" format=\"ascii\">\n";
+  for (auto const &e : elements) {
+    for (int j = 0; j < D; ++j)
+      f << (int)e[j] << " ";
+    f << "\n";
+  }
+  f << "        </DataArray>\n        <DataArray type=\"Int32\" Name=\"offsets\" format=\"ascii\">\n";
+  for (size_t i = 1; i <= elements.size(); ++i)
+    f << i * D << "\n";
+  f << "        </DataArray>\n      " << (D == 2 ? "</Lines>" : "</Polys>") << "\n";
+  if (flux.size() == elements.size() || flux.size() == points.size()) {
+    const bool cell = flux.size() == elements.size();
+    f << "      " << (cell ? "<CellData" : "<PointData") << " Scalars=\"flux\">\n"
+      << "        <DataArray type=\"Float32\" Name=\"flux\" format=\"ascii\">\n";
+    for (auto v : flux)
+      f << (float)v << "\n";
+    f << "        </DataArray>\n      " << (cell ? "</CellData>" : "</PointData>") << "\n";
+  } else {
+    std::cerr << "writeVTP: flux size does not match points or polys; skipping data\n";
+  }
+  f << "    </Piece>\n  </PolyData>\n</VTKFile>\n";
 }
 } // namespace rayInternal

@@ -717,7 +717,8 @@ struct Context {
 
   // Trace<T,D> state (rayTrace.hpp:157-179)
   int bcs[3] = {REFLECTIVE, REFLECTIVE, REFLECTIVE};
-  int sourceDirection = POS_Z;
+  int sourceDirectionUser = -1; // unset: D == 2 ? POS_Y : POS_Z (rayTrace.hpp:166-167)
+  int sourceDirection = POS_Z;  // effective, decided in prepare()
   bool usePrimaryDirection = false;
   Vec3 primaryDirection{0, 0, 0};
   int particleKind = DIFFUSE;
@@ -1309,6 +1310,7 @@ static void computeDiskAreas(Context &c) {
 // rayTraceTriangle.hpp:19-51)
 static void prepare(Context &c) {
   c.bdBox = {c.minC, c.maxC};
+  c.sourceDirection = c.sourceDirectionUser >= 0 ? c.sourceDirectionUser : (c.D == 2 ? POS_Y : POS_Z);
   adjustBoundingBox(c.bdBox, c.D, c.sourceDirection,
                     c.geoType == DISK ? c.diskRadius : c.gridDelta);
   c.ts = getTraceSettings(c.sourceDirection);
@@ -1485,7 +1487,7 @@ void orc_set_boundary_conditions(Context *c, const int *bcs, int n) {
   for (int i = 0; i < n && i < 3; ++i)
     c->bcs[i] = bcs[i];
 }
-void orc_set_source_direction(Context *c, int dir) { c->sourceDirection = dir; }
+void orc_set_source_direction(Context *c, int dir) { c->sourceDirectionUser = dir; }
 void orc_set_primary_direction(Context *c, const float *d) {
   if (d) {
     c->primaryDirection = {d[0], d[1], d[2]};

@@ -360,21 +360,51 @@ def test_gpu_shard_driver_matches_plain_apply():
         assert gi[k] == v
 
 
-def test_ported_reference_example_runs():
-    """The ported examples/disk3D program (reference API through the C++ façade)."""
+@pytest.mark.parametrize("name,data,rpp,rays", [("disk3D", "trenchGrid3D.dat", 50, 1445950),
+                                                ("disk2D", "trenchGrid2D.dat", 500, 119500),
+                                                ("triangle3D", "trenchMesh.dat", 20, 256000),
+                                                ("triangle2D", "lineMesh.dat", 400, 102400)])
+def test_ported_reference_example_runs(name, data, rpp, rays):
+    """The reference's four example programs, ported to the C++ façade (same API, other include
+    path), run on the fixture copies of the reference's data files."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "examples", "disk3D", "disk3D")
+    exe = os.path.join(root, "examples", name, name)
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.join(root, "examples")])
-    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "data", "trenchGrid3D.dat"), "50"],
-                         capture_output=True, text=True, cwd=str(root) + "/gpurun_out" if os.path.isdir(root + "/gpurun_out") else "/tmp",
-                         timeout=300)
+    cwd = os.path.join(root, "gpurun_out") if os.path.isdir(os.path.join(root, "gpurun_out")) else "/tmp"
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "data", data), str(rpp)],
+                         capture_output=True, text=True, cwd=cwd, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rays 1445950" in out.stdout
+    assert f"rays {rays}" in out.stdout, out.stdout
     mean = float(out.stdout.split("mean normalised flux")[1].split()[0])
     assert 0.05 < mean < 1.5
+
+
+@pytest.mark.parametrize("bc", [BC.REFLECTIVE_BOUNDARY, BC.PERIODIC_BOUNDARY])
+def test_line_mesh_2d(bc):
+    """examples/triangle2D: LineMesh -> triangle strips, TraceTriangle<D=2> (rayTraceTriangle.hpp:76-81)"""
+    import os
+    from helpers import DATA
+    gd, nodes, lines = vr.io.read_line_mesh(os.path.join(DATA, "lineMesh.dat"))
+    v, tri, keep = vr.io.lines_to_triangles(nodes, lines, gd)
+    assert lines.shape[0] == 130 and keep.size == 128  # 2 zero-length lines dropped (SURVEY appendix A)
+    t = vr.TraceTriangle(2)
+    t.setLineGeometry(nodes, lines, gd)
+    t.setBoundaryConditions([bc, bc])
+    t.setParticleType(vr.DiffuseParticle(0.1, "flux"))
+    t.setNumberOfRaysPerPoint(300)
+    t.setRngSeed(12345)
+    o = po.Oracle()
+    o.set_triangles(v, tri, gd, 2)
+    o.set_boundary_conditions([int(bc), int(bc)])
+    o.set_particle(po.DIFFUSE, 0.1)
+    o.set_num_rays_per_point(300)
+    o.set_rng_seed(12345)
+    o.set_lazy_rng(True)
+    err, gi = compare(t, o, counter_slack=0)
+    assert gi["numRays"] == 256 * 300 and gi["reflections"] > 0
 
 
 @pytest.mark.parametrize("geom", ["plane", "sphere", "trench3d", "trench2d"])

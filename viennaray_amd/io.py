@@ -69,3 +69,43 @@ def read_mesh(path, dim=3):
                 elems.append([int(v) for v in t[1:1 + dim]])
     return (grid_delta, np.array(nodes, dtype=np.float32),
             np.array(elems, dtype=np.uint32))
+
+
+def lines_to_triangles(nodes, lines, grid_delta):
+    """LineMesh -> TriangleMesh (rayMesh.hpp:27-80,133-175): zero-length lines are dropped,
+    every remaining line becomes a strip of two triangles of height grid_delta
+    (node 2i = node i at z = +grid_delta/2, node 2i+1 at z = -grid_delta/2).
+    Returns (vertices float32[2V,3], triangles uint32[2L,3], kept line indices)."""
+    nodes = np.ascontiguousarray(nodes, dtype=np.float32).reshape(-1, 3)
+    lines = np.ascontiguousarray(lines, dtype=np.uint32).reshape(-1, 2)
+    d = nodes[lines[:, 1]] - nodes[lines[:, 0]]
+    length = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2]).astype(np.float32))
+    keep = np.nonzero(length > np.float32(1e-6))[0]
+    w2 = np.float32(grid_delta) * np.float32(0.5)
+    verts = np.empty((2 * nodes.shape[0], 3), dtype=np.float32)
+    verts[0::2, :2] = nodes[:, :2]
+    verts[1::2, :2] = nodes[:, :2]
+    verts[0::2, 2] = w2
+    verts[1::2, 2] = -w2
+    p0 = lines[keep, 0] * 2
+    p1 = lines[keep, 1] * 2
+    tris = np.empty((2 * keep.size, 3), dtype=np.uint32)
+    tris[0::2] = np.stack([p0, p1, p0 + 1], 1)
+    tris[1::2] = np.stack([p0 + 1, p1, p1 + 1], 1)
+    return verts, tris, keep
+
+
+def read_line_mesh(path):
+    """2-D mesh file as the reference's reader sees it (rayUtil.hpp:374-411): elements the
+    file declares but does not hold stay (0, 0)."""
+    declared = None
+    with open(path) as fh:
+        for line in fh:
+            t = line.split()
+            if t and t[0] == "n_elements":
+                declared = int(t[1])
+                break
+    gd, nodes, lines = read_mesh(path, 2)
+    if declared is not None and lines.shape[0] < declared:
+        lines = np.concatenate([lines, np.zeros((declared - lines.shape[0], 2), np.uint32)])
+    return gd, nodes, lines

@@ -333,6 +333,12 @@ class TraceDisk(Trace):
 class TraceTriangle(Trace):
     """rayTraceTriangle.hpp:13-154"""
 
+    def setLineGeometry(self, nodes, lines, gridDelta):
+        """setGeometry(LineMesh) (rayTraceTriangle.hpp:76-81, D == 2): lines -> triangle strips"""
+        from . import io
+        v, t, _ = io.lines_to_triangles(nodes, lines, gridDelta)
+        self.setGeometry(v, t, gridDelta)
+
     def setGeometry(self, points, triangles, gridDelta):
         v = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
         t = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
