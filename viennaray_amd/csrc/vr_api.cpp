@@ -902,7 +902,7 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   {
     // bins per queue grab: ~1024 rays for big batches, but never so many that a small
     // batch (a short last one, a small launch) is handed to a few waves only
-    const uint64_t waves = (uint64_t)c->grid * (VR_BLOCK / 64);
+    const uint64_t waves = std::min<uint64_t>(c->grid, ((uint64_t)count + 255) / 256) * (VR_BLOCK / 64);
     p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, nbBatch / std::max<uint64_t>(waves * 2, 1)));
   }
   const bool tape = !c->absorb;
@@ -938,7 +938,10 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   }
   VR_HIP(c, hipMemsetAsync(p.workCounter, 0, 8, c->stream));
   VR_HIP(c, hipEventRecord(c->evK[2 * batchNo], c->stream));
-  VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->particleKind, c->absorb, c->grid, c->stream));
+  // a small batch does not need the whole persistent grid: one wave per 64 rays is plenty
+  const unsigned gridBatch =
+      (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(c->grid, ((uint64_t)count + 255) / 256));
+  VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->particleKind, c->absorb, gridBatch, c->stream));
   VR_HIP(c, hipEventRecord(c->evK[2 * batchNo + 1], c->stream));
   if (c->overlap)
     VR_HIP(c, hipEventRecord(c->evTraced[batchNo], c->stream));
