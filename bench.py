@@ -153,12 +153,14 @@ def main():
         abytes, b_hit, b_path = algorithmic_bytes(N, float(np.mean(geo)), float(np.mean(segs)))
         achieved = abytes / (tavg * 1e-3) / 1e9
         traffic = None
+        valu_frac = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("grid") == n and tj.get("rays") == args.rays and tj.get("sticking") == args.sticking:
                     traffic = tj.get("hbm_bytes_per_launch")  # (2*FETCH_SIZE + WRITE_SIZE) * 1024, trace_kernel
+                    valu_frac = tj.get("valu_issue_frac")     # same profile: VALU issue occupancy
             except Exception:
                 traffic = None
         out = {
@@ -177,6 +179,7 @@ def main():
             "roofline": {"kernel": "trace_kernel", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "bytes_per_hit_segment": round(b_hit, 1), "bytes_per_other_segment": b_path,
+                         "valu_issue_frac": (round(valu_frac, 3) if valu_frac else None),
                          "note": "achieved = SURVEY 8(d) algorithmic bytes / trace_kernel time; sorted rays fetch nodes and "
                                  "disks wave-uniformly through the scalar cache, so measured fabric traffic is far below "
                                  "the algorithmic bytes and frac can exceed 1: the kernel is VALU-issue bound (DESIGN.md 7)"},

@@ -44,6 +44,29 @@ if len(vals) == 2:
     out = {"kernel": "trace_kernel", "fetch_size_kb": vals["FETCH_SIZE"], "write_size_kb": vals["WRITE_SIZE"],
            "hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
            "note": "(2*FETCH_SIZE + WRITE_SIZE)*1024 per main trace_kernel launch; fabric requests incl. Infinity-Cache hits"}
+    # VALU issue occupancy of the same launches: wave-instructions x 4 cycles (wave64 on a 16-lane
+    # SIMD) / (duration x 2.4 GHz x 1024 SIMDs) — what actually bounds the sorted-ray kernel
+    try:
+        valu = []
+        for f in glob.glob(os.path.join(d, "pmc_SQ_INSTS_VALU*", "**", "*counter_collection.csv"), recursive=True):
+            per = defaultdict(float)
+            for r in csv.DictReader(open(f)):
+                if "trace_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == "SQ_INSTS_VALU":
+                    per[r.get("Dispatch_Id")] += float(r.get("Counter_Value", 0))
+            top = max(per.values())
+            valu = [v for v in per.values() if v > 0.1 * top]
+        dur = []
+        for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "trace_kernel" in r.get("Kernel_Name", ""):
+                    dur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        dur = [x for x in dur if x > 0.1 * max(dur)]
+        if valu and dur:
+            out["valu_insts_per_launch"] = sum(valu) / len(valu)
+            out["avg_launch_ns"] = sum(dur) / len(dur)
+            out["valu_issue_frac"] = out["valu_insts_per_launch"] * 4 / (out["avg_launch_ns"] * 1e-9 * 2.4e9 * 1024)
+    except Exception as e:
+        print("no VALU occupancy:", e)
     # the workload the numbers belong to (bench.py only quotes them for the same one)
     try:
         line = [l for l in open(os.path.join(d, "stats.log")) if l.startswith("{")][-1]
