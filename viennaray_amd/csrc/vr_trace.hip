@@ -300,19 +300,27 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
 //  MI355X_MICROARCH.md; 80 keeps 8 blocks resident)
 template <int D, int GEO, int PARTICLE, bool ABSORB>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
-__attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_kernel(const TraceParams p) {
+__attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 6, ABSORB ? 8 : 6))) void trace_kernel(const TraceParams p) {
   // CARRY: lanes whose BVH walk is still under way when most of the wave is done keep
   // their cursor over the state-machine / refill phase (see the round structure below).
   // The absorbing kernel does without: its rounds are packets or short walks, and the
   // extra live registers would cost it the 8th wave per SIMD.
   constexpr bool CARRY = !ABSORB;
   __shared__ float wallS[96];
+  // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
+  __shared__ unsigned cntS[8 * VR_BLOCK];
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
   if (tid < 96)
     wallS[tid] = p.wallTable[tid];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    cntS[k * VR_BLOCK + tid] = 0u;
   __syncthreads();
+  unsigned *const cnt = cntS + tid; // counter k of this lane: cnt[k * VR_BLOCK]
+  enum { K_TRACES = 0, K_NONGEO, K_GEO, K_BOUNDARY, K_REFL, K_TERM, K_TIER2 };
+#define VR_COUNT(k, v) atomicAdd(&cnt[(k) * VR_BLOCK], (unsigned)(v))
 
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
   const float4 *__restrict__ rayAB = reinterpret_cast<const float4 *>(p.slotRec);
@@ -321,7 +329,10 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
 
   // per-lane ray state
   bool active = false;
-  V3 org = mk(0, 0, 0), rayDirection = mk(0, 0, 1), dir = mk(0, 0, 1);
+  // `dir` is what the intersector sees: the 2-D projection of rayDirection (rayUtil.hpp:204-227),
+  // i.e. rayDirection itself in 3-D (then the same registers)
+  V3 org = mk(0, 0, 0), rayDirection = mk(0, 0, 1), dir2 = mk(0, 0, 1);
+  V3 &dir = D == 3 ? rayDirection : dir2;
   float rayWeight = 0.f;
   unsigned numReflections = 0, boundaryHits = 0;
   bool hitFromBack = false;
@@ -335,8 +346,6 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
   Rng rng;
   rng_resume(rng, 0u, 0u, 0ull, 0ull);
   rng.scratch = p.rngScratch + (size_t)gwave * (312u * 64u) + lane;
-  // counters
-  unsigned cTraces = 0, cNongeo = 0, cGeo = 0, cBoundary = 0, cRefl = 0, cTerm = 0, cTier2 = 0;
   // wave-uniform cursor over the sort bins: [curBin, spanEnd) is the span of (virtual)
   // bins this wave pulled from the queue; bins >= numBins are 64-ray chunks of the
   // overflow region
@@ -472,15 +481,15 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
     if (fin) {
       DIAG(5);
       // ---- the reference's state machine for this segment (rayTraceKernel.hpp:169-335) ----
-      ++cTraces;
+      VR_COUNT(K_TRACES, 1);
       if (h.geom < 0) { // miss, :172-176
-        ++cNongeo;
+        VR_COUNT(K_NONGEO, 1);
         active = false;
       } else {
         const V3 hitPoint = mk(org.x + dir.x * h.t, org.y + dir.y * h.t, org.z + dir.z * h.t);
         if (h.geom == 0) { // boundary, :206-214 + rayBoundary.hpp:29-127
           if (++boundaryHits > p.maxBoundaryHits) {
-            ++cTerm;
+            VR_COUNT(K_TERM, 1);
             active = false;
           } else {
             const float *w = wallS + 12 * h.prim;
@@ -529,11 +538,11 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
               hitFromBack = true;
               org = hitPoint;
             } else { // :229-233, :243-248
-              ++cTerm;
+              VR_COUNT(K_TERM, 1);
               active = false;
             }
           } else {
-            ++cGeo;
+            VR_COUNT(K_GEO, 1);
             DIAG(11);
             const u64 wfx = weight_fx(rayWeight);
             // surfaceCollision, rayParticle.hpp:148-156
@@ -571,12 +580,12 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
                 // surfaceReflection, rayParticle.hpp:137-146 / 178-187
                 V3 newDir;
                 if (PARTICLE == 0)
-                  newDir = reflect_diffuse<D>(geomNormal, rng, cTier2 VR_DIAG_PASS);
+                  newDir = reflect_diffuse<D>(geomNormal, rng, cnt[K_TIER2 * VR_BLOCK] VR_DIAG_PASS);
                 else
                   newDir = reflect_specular(rayDirection, geomNormal);
                 rayWeight = wAfter;
                 if (++numReflections > p.maxReflections) { // :320-324
-                  ++cTerm;
+                  VR_COUNT(K_TERM, 1);
                   active = false;
                 } else {
                   // rejectionControl, :435-460
@@ -586,7 +595,7 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
                   if (!(rayWeight >= lowerThreshold)) {
                     DIAG(10);
                     const double killProbability = 1.0 - (double)(rayWeight / renewWeight);
-                    if (canon_f64(rng_next(rng, cTier2)) < killProbability)
+                    if (canon_f64(rng_next(rng, cnt[K_TIER2 * VR_BLOCK])) < killProbability)
                       reflect = false;
                     else
                       rayWeight = renewWeight;
@@ -605,8 +614,8 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
         }
       }
       if (!active) {
-        cBoundary += boundaryHits;
-        cRefl += numReflections;
+        VR_COUNT(K_BOUNDARY, boundaryHits);
+        VR_COUNT(K_REFL, numReflections);
       }
       start = active; // still alive: the next segment begins in the next round
     }
@@ -621,7 +630,11 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 5, ABSORB ? 8 : 5))) void trace_
     }
   }
 #endif
-  const unsigned vals[8] = {cTraces, cNongeo, cGeo, 0u, cBoundary, cRefl, cTerm, cTier2};
+  // (slot order of vr_types.hpp: traces, nongeo, geo, particle, boundary, reflections, terminated, tier2)
+  const unsigned vals[8] = {cnt[K_TRACES * VR_BLOCK], cnt[K_NONGEO * VR_BLOCK], cnt[K_GEO * VR_BLOCK], 0u,
+                            cnt[K_BOUNDARY * VR_BLOCK], cnt[K_REFL * VR_BLOCK], cnt[K_TERM * VR_BLOCK],
+                            cnt[K_TIER2 * VR_BLOCK]};
+#undef VR_COUNT
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const unsigned long long s = wave_sum(vals[i]);
