@@ -474,9 +474,20 @@ __attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 6, ABSORB ? 8 : 6))) void trace_
     const bool fin = active && node >= p.numNodes; // this lane's geometry walk is complete
     if (fin)
       hit_walls(p, wallS, org, dir, tnear, h); // boundary walls, where one can come before the hit
-    // merge same-disk credits of the wave into one atomic when that is likely to pay: rays
-    // of a packet (small scenes spread their credits over accumulator replicas instead)
-    const bool aggregate = packetDone;
+    // Merge same-disk credits of the wave into one atomic when that is likely to pay: rays of a
+    // packet, or — sampled on one lane's target — when a good share of the wave's hits fall on
+    // the same primitive (sorted rays on a coarse scene: one vector atomic with 64 lanes on ONE
+    // address is serialised lane by lane in the L2 atomic unit).
+    bool aggregate = packetDone;
+    {
+      const bool cand = fin && h.geom == 1;
+      const unsigned long long cm = __ballot(cand);
+      if (!aggregate && cm) {
+        const unsigned sample = (unsigned)__shfl((int)h.pos, __ffsll((long long)cm) - 1, 64);
+        const unsigned same = (unsigned)__popcll(__ballot(cand && h.pos == sample));
+        aggregate = 4u * same >= (unsigned)__popcll(cm) && same >= 4u;
+      }
+    }
 
     if (fin) {
       DIAG(5);
