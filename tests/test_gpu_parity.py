@@ -473,11 +473,12 @@ SCHEDULING_KNOBS = [
     {"VR_NO_CHILD_ORDER": "1"},
     {"VR_TRACE_BLOCKS": "1"},
     {"VR_KEY_COORD": "-7.5"},
+    {"VR_ABSORB_CARRY": "0"}, {"VR_ABSORB_CARRY": "1"},
 ]
 
 
-@pytest.mark.parametrize("geom", ["trench3d", "mesh", "trench2d"])
-def test_scheduling_knobs_do_not_change_results(geom, monkeypatch):
+@pytest.mark.parametrize("geom,sticking", [("trench3d", 0.15), ("mesh", 0.15), ("trench2d", 0.15), ("trench3d", 1.0)])
+def test_scheduling_knobs_do_not_change_results(geom, sticking, monkeypatch):
     """Ray order, batching, bin geometry, packet / per-lane traversal policy, BVH leaf size and
     child order, accumulator replication: none of it may change a single accumulator bit or
     counter (int64 fixed-point sums + the order-independent closest-hit rule)."""
@@ -501,13 +502,13 @@ def test_scheduling_knobs_do_not_change_results(geom, monkeypatch):
             t.setGeometry(p, n, gd)
             t.setBoundaryConditions([BC.REFLECTIVE_BOUNDARY, BC.PERIODIC_BOUNDARY, BC.PERIODIC_BOUNDARY])
             t.setNumberOfRaysPerPoint(12)
-        t.setParticleType(vr.DiffuseParticle(0.15, "flux"))
+        t.setParticleType(vr.DiffuseParticle(sticking, "flux"))
         t.setRngSeed(99)
         t.apply()
         return t.getFluxF64(), info_dict(t)
 
     f0, i0 = run()
-    assert i0["reflections"] > 0 and i0["boundaryHits"] > 0
+    assert (i0["reflections"] > 0 or sticking >= 1.0) and i0["boundaryHits"] > 0
     for knobs in SCHEDULING_KNOBS:
         with monkeypatch.context() as m:
             for k, v in knobs.items():

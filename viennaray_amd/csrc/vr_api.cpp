@@ -110,6 +110,8 @@ struct vr_context {
   uint32_t numNodes = 0;         // traversal nodes emitted by the builder
   float qbase[3] = {0, 0, 0}, qscale[3] = {0, 0, 0}; // frame of the 16-byte nodes
   float keyCoord = 0.f;          // sort plane of the ray stream on the tracing axis (host_sort_plane)
+  float keyShare = 1.f;          // share of the surface shown to the source that lies in that plane
+  int traceMode = 0;             // trace_kernel MODE of the prepared launch
   int builtOrderAxis = -1;       // child order of the resident BVH (source side first)
   float builtOrderSign = 0.f;
   DevBuf<unsigned long long> dKeysA, dKeysB;
@@ -673,7 +675,8 @@ int vr_apply_prepare(vr_context *c) {
     // SourceRandom::getSourceArea (raySourceRandom.hpp:40-47)
     const int f = c->ts[1], s = c->ts[2];
     c->sourceArea = D == 2 ? (c->bbHi[f] - c->bbLo[f]) : (c->bbHi[f] - c->bbLo[f]) * (c->bbHi[s] - c->bbLo[s]);
-    c->keyCoord = host_sort_plane(c->geo, c->ts[0], c->ts[3] ? c->geo.minC[c->ts[0]] : c->geo.maxC[c->ts[0]]);
+    c->keyCoord = host_sort_plane(c->geo, c->ts[0], c->ts[3] ? c->geo.minC[c->ts[0]] : c->geo.maxC[c->ts[0]],
+                                 &c->keyShare);
   }
 
   const uint32_t N = c->geo.numPrims;
@@ -771,7 +774,13 @@ int vr_apply_prepare(vr_context *c) {
 
   // launch geometry of the persistent kernels
   {
-    int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->particleKind, c->absorb));
+    // absorbing particles: a (nearly) flat surface is served by packets alone; a structured one
+    // ends most rounds in per-lane walks and wants the straggler carry-over (MODE 2)
+    c->traceMode = !c->absorb ? 0 : (c->keyShare >= 0.95f ? 1 : 2);
+    if (const char *e = std::getenv("VR_ABSORB_CARRY"))
+      if (c->absorb)
+        c->traceMode = std::atoi(e) ? 2 : 1;
+    int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->particleKind, c->traceMode));
     if (c->overlap && blocks > 4)
       blocks -= 2; // leave wave slots for the concurrently running generator / sorter
     if (const char *e = std::getenv("VR_TRACE_BLOCKS"))
@@ -941,7 +950,7 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   // a small batch does not need the whole persistent grid: one wave per 64 rays is plenty
   const unsigned gridBatch =
       (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(c->grid, ((uint64_t)count + 255) / 256));
-  VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->particleKind, c->absorb, gridBatch, c->stream));
+  VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->particleKind, c->traceMode, gridBatch, c->stream));
   VR_HIP(c, hipEventRecord(c->evK[2 * batchNo + 1], c->stream));
   if (c->overlap)
     VR_HIP(c, hipEventRecord(c->evTraced[batchNo], c->stream));

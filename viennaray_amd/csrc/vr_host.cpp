@@ -419,8 +419,10 @@ void host_disk_areas(const HostGeometry &g, const int *bc2, int firstDir, int se
   }
 }
 
-float host_sort_plane(const HostGeometry &g, int axis, float fallback) {
+float host_sort_plane(const HostGeometry &g, int axis, float fallback, float *modeShare) {
   const float lo = g.minC[axis], hi = g.maxC[axis];
+  if (modeShare)
+    *modeShare = 1.f;
   if (g.numPrims == 0 || !(hi > lo))
     return g.numPrims ? lo : fallback;
   constexpr int SL = 256;
@@ -450,9 +452,14 @@ float host_sort_plane(const HostGeometry &g, int axis, float fallback) {
     wh[k] += a * h;
   }
   int best = 0;
-  for (int k = 1; k < SL; ++k)
+  double total = w[0];
+  for (int k = 1; k < SL; ++k) {
+    total += w[k];
     if (w[k] > w[best])
       best = k;
+  }
+  if (modeShare && total > 0.)
+    *modeShare = (float)(w[best] / total);
   return w[best] > 0. ? (float)(wh[best] / w[best]) : fallback;
 }
 

@@ -46,7 +46,8 @@ void host_set_triangles(HostGeometry &g, const float *verts, uint32_t nv, const 
 // primitives' coordinates on the axis, weighted by the area they show the source
 // (r^2 |n_axis| for a disc, |Ng_axis| / 2 for a triangle); the weighted mean of the
 // fullest of 256 slices.  (Only orders the work: no influence on any result.)
-float host_sort_plane(const HostGeometry &g, int axis, float fallback);
+float host_sort_plane(const HostGeometry &g, int axis, float fallback, float *modeShare = nullptr);
+// (*modeShare: the fullest slice's share of the total shown area; ~1 for a flat surface)
 // rayPointNeighborhood.hpp:42-107 as a CSR (all pairs within `dist`)
 void host_neighbors(int D, const float *pts3, uint32_t n, float dist, const float *minC, std::vector<uint32_t> &off,
                     std::vector<uint32_t> &ids);

@@ -298,14 +298,18 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
 // ---------------------------------------------------------------------------
 // (SGPR budget: 256-thread blocks per CU = min(8, 800 / (ceil(sgpr/16)*16 + 16)) on gfx950,
 //  MI355X_MICROARCH.md; 80 keeps 8 blocks resident)
-template <int D, int GEO, int PARTICLE, bool ABSORB>
+// MODE 0: general kernel.  MODE 1: absorbing, flat scene (packets carry the load).  MODE 2:
+// absorbing, structured scene (most rounds end in per-lane walks): straggler carry-over on.
+template <int D, int GEO, int PARTICLE, int MODE>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
-__attribute__((amdgpu_waves_per_eu(ABSORB ? 8 : 6, ABSORB ? 8 : 6))) void trace_kernel(const TraceParams p) {
+__attribute__((amdgpu_waves_per_eu(MODE == 1 ? 8 : (MODE == 2 ? 7 : 6), MODE == 1 ? 8 : (MODE == 2 ? 7 : 6)))) void
+trace_kernel(const TraceParams p) {
+  constexpr bool ABSORB = MODE != 0;
   // CARRY: lanes whose BVH walk is still under way when most of the wave is done keep
   // their cursor over the state-machine / refill phase (see the round structure below).
-  // The absorbing kernel does without: its rounds are packets or short walks, and the
-  // extra live registers would cost it the 8th wave per SIMD.
-  constexpr bool CARRY = !ABSORB;
+  // The absorbing kernel for flat scenes does without: its rounds are packets, and the extra
+  // live registers would cost it the 8th wave per SIMD.
+  constexpr bool CARRY = MODE != 1;
   __shared__ float wallS[96];
   // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
   __shared__ unsigned cntS[8 * VR_BLOCK];
@@ -692,54 +696,60 @@ hipError_t launch_scan(unsigned *data, unsigned n, unsigned *tmp /* >= 2 * ceil(
 }
 
 template <int D, int GEO, int PARTICLE>
-static hipError_t launch_trace_t(const TraceParams &p, bool absorb, unsigned grid, hipStream_t s) {
-  if (absorb)
-    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, hipStream_t s) {
+  if (mode == 1)
+    hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 1>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  else if (mode == 2)
+    hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 2>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else
-    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   return hipGetLastError();
 }
 
-hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, bool absorb, unsigned grid,
+// mode: 0 general, 1 absorbing + flat scene, 2 absorbing + structured scene
+hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int mode, unsigned grid,
                         hipStream_t s) {
+  const bool absorb = mode != 0;
   if (absorb)
     particle = 0; // the reflection model is unobservable: one instantiation serves both
   const int key = (D == 2 ? 0 : 4) | (geo ? 2 : 0) | (particle ? 1 : 0);
   switch (key) {
-  case 0: return launch_trace_t<2, 0, 0>(p, absorb, grid, s);
-  case 1: return launch_trace_t<2, 0, 1>(p, absorb, grid, s);
-  case 2: return launch_trace_t<2, 1, 0>(p, absorb, grid, s);
-  case 3: return launch_trace_t<2, 1, 1>(p, absorb, grid, s);
-  case 4: return launch_trace_t<3, 0, 0>(p, absorb, grid, s);
-  case 5: return launch_trace_t<3, 0, 1>(p, absorb, grid, s);
-  case 6: return launch_trace_t<3, 1, 0>(p, absorb, grid, s);
-  default: return launch_trace_t<3, 1, 1>(p, absorb, grid, s);
+  case 0: return launch_trace_t<2, 0, 0>(p, mode, grid, s);
+  case 1: return launch_trace_t<2, 0, 1>(p, mode, grid, s);
+  case 2: return launch_trace_t<2, 1, 0>(p, mode, grid, s);
+  case 3: return launch_trace_t<2, 1, 1>(p, mode, grid, s);
+  case 4: return launch_trace_t<3, 0, 0>(p, mode, grid, s);
+  case 5: return launch_trace_t<3, 0, 1>(p, mode, grid, s);
+  case 6: return launch_trace_t<3, 1, 0>(p, mode, grid, s);
+  default: return launch_trace_t<3, 1, 1>(p, mode, grid, s);
   }
 }
 
-template <int D, int GEO, int PARTICLE> static int occ_t(bool absorb) {
+template <int D, int GEO, int PARTICLE> static int occ_t(int mode) {
   int nb = 0;
   hipError_t e;
-  if (absorb)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, true>, VR_BLOCK, 0);
+  if (mode == 1)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 1>, VR_BLOCK, 0);
+  else if (mode == 2)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 2>, VR_BLOCK, 0);
   else
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, false>, VR_BLOCK, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 0>, VR_BLOCK, 0);
   return e == hipSuccess ? nb : 2;
 }
 
-int trace_blocks_per_cu(int D, int geo, int particle, bool absorb) {
-  if (absorb)
+int trace_blocks_per_cu(int D, int geo, int particle, int mode) {
+  if (mode != 0)
     particle = 0;
   const int key = (D == 2 ? 0 : 4) | (geo ? 2 : 0) | (particle ? 1 : 0);
   switch (key) {
-  case 0: return occ_t<2, 0, 0>(absorb);
-  case 1: return occ_t<2, 0, 1>(absorb);
-  case 2: return occ_t<2, 1, 0>(absorb);
-  case 3: return occ_t<2, 1, 1>(absorb);
-  case 4: return occ_t<3, 0, 0>(absorb);
-  case 5: return occ_t<3, 0, 1>(absorb);
-  case 6: return occ_t<3, 1, 0>(absorb);
-  default: return occ_t<3, 1, 1>(absorb);
+  case 0: return occ_t<2, 0, 0>(mode);
+  case 1: return occ_t<2, 0, 1>(mode);
+  case 2: return occ_t<2, 1, 0>(mode);
+  case 3: return occ_t<2, 1, 1>(mode);
+  case 4: return occ_t<3, 0, 0>(mode);
+  case 5: return occ_t<3, 0, 1>(mode);
+  case 6: return occ_t<3, 1, 0>(mode);
+  default: return occ_t<3, 1, 1>(mode);
   }
 }
 
