@@ -177,6 +177,9 @@ int vr_debug_rng_outputs(vr_context *ctx, uint64_t idx, uint32_t seed,
                          uint32_t count, uint64_t *out);
 /* BVH statistics: nodes, leaves, max depth */
 int vr_debug_bvh_stats(vr_context *ctx, uint32_t *out3);
+/* consistency of the resident device-built BVH: number of internal nodes whose box is not
+ * exactly the union of their children's or whose subtree size is inconsistent (expected 0)  */
+int vr_debug_bvh_check(vr_context *ctx, uint32_t *violations);
 
 #ifdef __cplusplus
 }

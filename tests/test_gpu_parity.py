@@ -600,3 +600,28 @@ def test_long_bounce_chains_use_the_full_engine_state():
     err, gi = compare(t, o, counter_slack=0)
     assert gi["reflections"] > 50 * gi["numRays"]
     assert t.getRayTraceInfo().rngFullStates > 1000  # the tier was really exercised
+
+
+def test_device_bvh_is_consistent_after_every_rebuild():
+    """The bottom-up fit hands boxes from one workgroup to another with atomic stores and a
+    wait instead of an L2 write-back fence (vr_setup.hip, fit_kernel): every internal box must
+    still be exactly the union of its children's, on a big scene, on every rebuild."""
+    pts, nrm = vr.io.plane_grid(700, 1.0)
+    rng = np.random.default_rng(3)
+    t = vr.TraceDisk(3)
+    t.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+    t.setNumberOfRaysFixed(1000)
+    for it in range(6):
+        p = pts.copy()
+        p[:, 2] = rng.normal(scale=0.3, size=p.shape[0]).astype(np.float32)  # a new rough surface
+        t.setGeometry(p, nrm, 1.0)
+        t.applyPrepare()
+        assert t.debugBvhCheck() == 0
+        t.applyLaunch()
+        t.applyFinish()
+    gd, v, tri = trench_mesh()
+    m = vr.TraceTriangle(3)
+    m.setGeometry(v, tri, gd)
+    m.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+    m.applyPrepare()
+    assert m.debugBvhCheck() == 0

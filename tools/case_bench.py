@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times one apply() of a named fixture geometry on the GPU.
-usage: tools/case_bench.py <trench3d|trench2d|mesh|plane100> <sticking> <raysPerPoint> [repeat]"""
+usage: tools/case_bench.py <trench3d|trench2d|mesh|plane100> <sticking> <raysPerPoint> [repeat]
+       tools/case_bench.py <C4|C5p|C5r> [repeat]      (SURVEY.md 8d configs, 1e8 rays)"""
 import sys, os, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,9 +10,25 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import viennaray_amd as vr
 from helpers import trench3d, trench2d, trench_mesh
 
-case, sticking, rpp = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
-rep = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-if case == "mesh":
+case = sys.argv[1]
+fixed = None
+particle = None
+if case in ("C4", "C5p", "C5r"):
+    rep = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    sticking, rpp, fixed = 0.1, 0, 100_000_000
+else:
+    sticking, rpp = float(sys.argv[2]), int(sys.argv[3])
+    rep = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+if case == "C4":   # trenchMesh.dat, SpecularParticle(0.1, power 50), default REFLECTIVE walls
+    gd, v, tri = trench_mesh()
+    t = vr.TraceTriangle(3); t.setGeometry(v, tri, gd)
+    particle = vr.SpecularParticle(0.1, 50.0, "flux")
+elif case in ("C5p", "C5r"):   # trenchGrid2D.dat, D=2, POS_Y, diffuse 0.1, periodic / reflective in x
+    gd, p, n = trench2d()
+    t = vr.TraceDisk(2); t.setGeometry(p, n, gd); t.setSourceDirection(vr.TraceDirection.POS_Y)
+    bc = vr.BoundaryCondition.PERIODIC_BOUNDARY if case == "C5p" else vr.BoundaryCondition.REFLECTIVE_BOUNDARY
+    t.setBoundaryConditions([bc] * 2)
+elif case == "mesh":
     gd, v, tri = trench_mesh()
     t = vr.TraceTriangle(3); t.setGeometry(v, tri, gd)
 elif case == "trench2d":
@@ -24,8 +41,11 @@ elif case == "plane100":
 else:
     gd, p, n = trench3d()
     t = vr.TraceDisk(3); t.setGeometry(p, n, gd); t.setBoundaryConditions([vr.BoundaryCondition.PERIODIC_BOUNDARY] * 3)
-t.setParticleType(vr.DiffuseParticle(sticking, "flux"))
-t.setNumberOfRaysPerPoint(rpp)
+t.setParticleType(particle if particle is not None else vr.DiffuseParticle(sticking, "flux"))
+if fixed:
+    t.setNumberOfRaysFixed(fixed)
+else:
+    t.setNumberOfRaysPerPoint(rpp)
 t.setRngSeed(12345)
 for i in range(rep):
     t.setRunNumber(1)

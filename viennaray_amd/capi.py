@@ -87,6 +87,7 @@ SIGNATURES = {
     "vr_debug_source_sample": (C.c_int, [_vp, _u64p, C.c_uint32, C.c_uint32, _fp, _fp]),
     "vr_debug_rng_outputs": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, _u64p]),
     "vr_debug_bvh_stats": (C.c_int, [_vp, _u32p]),
+    "vr_debug_bvh_check": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
 }
 
 _lib = None

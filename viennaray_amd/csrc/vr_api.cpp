@@ -112,6 +112,8 @@ struct vr_context {
   float keyCoord = 0.f;          // sort plane of the ray stream on the tracing axis (host_sort_plane)
   float keyShare = 1.f;          // share of the surface shown to the source that lies in that plane
   int traceMode = 0;             // trace_kernel MODE of the prepared launch
+  SetupParams lastSetup{};       // buffers of the resident device build (vr_debug_bvh_check)
+  bool haveSetup = false;
   int builtOrderAxis = -1;       // child order of the resident BVH (source side first)
   float builtOrderSign = 0.f;
   DevBuf<unsigned long long> dKeysA, dKeysB;
@@ -583,6 +585,8 @@ static int build_scene(vr_context *c) {
   s.nbOff = c->dNbOff.p;
   s.nbIds = nullptr;
   VR_HIP(c, launch_setup_bvh(s, c->dScanTmp.p, c->stream));
+  c->lastSetup = s;
+  c->haveSetup = true;
   if (disk) {
     // neighbourhood: count -> scan -> fill
     VR_HIP(c, hipMemsetAsync(c->dNbOff.p + N, 0, 4, c->stream));
@@ -1308,6 +1312,21 @@ int vr_debug_rng_outputs(vr_context *c, uint64_t idx, uint32_t seed, uint32_t co
   VR_HIP(c, hipMemcpy(out, dOut.p, (size_t)count * 8, hipMemcpyDeviceToHost));
   dS.release();
   dOut.release();
+  return VR_OK;
+}
+
+int vr_debug_bvh_check(vr_context *c, uint32_t *violations) {
+  if (!c || !violations)
+    return VR_E_INVALID;
+  if (!c->haveSetup || c->geometryDirty)
+    return fail(c, VR_E_STATE, "vr_debug_bvh_check: no device-built BVH resident (call vr_apply_prepare)");
+  VR_HIP(c, hipSetDevice(c->device));
+  DevBuf<uint32_t> dBad;
+  VR_HIP(c, dBad.ensure(1));
+  VR_HIP(c, hipMemsetAsync(dBad.p, 0, 4, c->stream));
+  VR_HIP(c, launch_bvh_check(c->lastSetup, dBad.p, c->stream));
+  VR_HIP(c, hipMemcpyAsync(violations, dBad.p, 4, hipMemcpyDeviceToHost, c->stream));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
   return VR_OK;
 }
 

@@ -19,6 +19,7 @@ hipError_t launch_debug_rng(unsigned seed32, unsigned count, unsigned long long 
                             hipStream_t s);
 // device-side setup (vr_setup.hip)
 hipError_t launch_setup_bvh(const SetupParams &s, unsigned *scanTmp, hipStream_t st);
+hipError_t launch_bvh_check(const SetupParams &s, unsigned *bad, hipStream_t st);
 hipError_t launch_quantize_nodes(const float *nodes, unsigned numNodes, const float *base3, const float *scale3,
                                  uint32_t *qnodes, hipStream_t st);
 hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st);

@@ -294,6 +294,11 @@ class Trace:
                                                  out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out
 
+    def debugBvhCheck(self):
+        v = C.c_uint32(0)
+        self._check(self._L.vr_debug_bvh_check(self._h, C.byref(v)))
+        return int(v.value)
+
     def debugBvhStats(self):
         a = (C.c_uint32 * 3)()
         self._check(self._L.vr_debug_bvh_stats(self._h, a))
