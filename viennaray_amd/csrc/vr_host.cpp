@@ -8,6 +8,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -38,6 +39,26 @@ inline void normalize3(F3 &a) {
 // ---------------------------------------------------------------------------
 // geometry ingestion
 // ---------------------------------------------------------------------------
+// splits [0, n) over a few host threads (the per-geometry host loops run once per new point
+// cloud, on 10^6+ points: bbox, disk areas, sort-plane histogram); fn(thread, begin, end)
+template <class F> static void parallel_ranges(uint32_t n, F fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  unsigned nt = n < (1u << 16) ? 1u : std::min(16u, std::max(1u, hw));
+  if (nt <= 1) {
+    fn(0u, 0u, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const uint32_t chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; ++t) {
+    const uint32_t b = std::min<uint64_t>((uint64_t)t * chunk, n), e = std::min<uint64_t>((uint64_t)(t + 1) * chunk, n);
+    th.emplace_back([=] { fn(t, b, e); });
+  }
+  for (auto &x : th)
+    x.join();
+}
+constexpr unsigned kMaxHostThreads = 16;
+
 void host_set_disks(HostGeometry &g, const float *pts, const float *nrm, uint32_t n, float gridDelta, float radius,
                     int D) {
   g.D = D;
@@ -56,21 +77,39 @@ void host_set_disks(HostGeometry &g, const float *pts, const float *nrm, uint32_
   }
   if (D == 2)
     g.minC[2] = g.maxC[2] = 0.f;
-  for (uint32_t i = 0; i < n; ++i) {
-    const float *p = pts + 3 * (size_t)i;
-    float *d = &g.disk4[4 * (size_t)i];
-    d[0] = p[0];
-    d[1] = p[1];
-    d[2] = D == 2 ? 0.f : p[2];
-    d[3] = g.diskRadius;
-    for (int k = 0; k < D; ++k) {
-      g.minC[k] = std::min(g.minC[k], p[k]);
-      g.maxC[k] = std::max(g.maxC[k], p[k]);
+  float tmin[kMaxHostThreads][3], tmax[kMaxHostThreads][3];
+  for (unsigned t = 0; t < kMaxHostThreads; ++t)
+    for (int k = 0; k < 3; ++k) {
+      tmin[t][k] = std::numeric_limits<float>::max();
+      tmax[t][k] = std::numeric_limits<float>::lowest();
     }
-    g.normal3[3 * (size_t)i + 0] = nrm[3 * (size_t)i + 0];
-    g.normal3[3 * (size_t)i + 1] = nrm[3 * (size_t)i + 1];
-    g.normal3[3 * (size_t)i + 2] = D == 2 ? 0.f : nrm[3 * (size_t)i + 2];
-  }
+  parallel_ranges(n, [&](unsigned t, uint32_t b, uint32_t e) {
+    float lmin[3] = {tmin[t][0], tmin[t][1], tmin[t][2]}, lmax[3] = {tmax[t][0], tmax[t][1], tmax[t][2]};
+    for (uint32_t i = b; i < e; ++i) {
+      const float *p = pts + 3 * (size_t)i;
+      float *d = &g.disk4[4 * (size_t)i];
+      d[0] = p[0];
+      d[1] = p[1];
+      d[2] = D == 2 ? 0.f : p[2];
+      d[3] = g.diskRadius;
+      for (int k = 0; k < D; ++k) { // (thread-local: the shared arrays would ping-pong between cores)
+        lmin[k] = std::min(lmin[k], p[k]);
+        lmax[k] = std::max(lmax[k], p[k]);
+      }
+      g.normal3[3 * (size_t)i + 0] = nrm[3 * (size_t)i + 0];
+      g.normal3[3 * (size_t)i + 1] = nrm[3 * (size_t)i + 1];
+      g.normal3[3 * (size_t)i + 2] = D == 2 ? 0.f : nrm[3 * (size_t)i + 2];
+    }
+    for (int k = 0; k < 3; ++k) {
+      tmin[t][k] = lmin[k];
+      tmax[t][k] = lmax[k];
+    }
+  });
+  for (unsigned t = 0; t < kMaxHostThreads; ++t)
+    for (int k = 0; k < D; ++k) { // (min/max: any order gives the same result)
+      g.minC[k] = std::min(g.minC[k], tmin[t][k]);
+      g.maxC[k] = std::max(g.maxC[k], tmax[t][k]);
+    }
   if (g.materialIds.size() != n)
     g.materialIds.assign(n, 0);
   // the neighbourhood (rayGeometryDisk.hpp:191-192, radius = 2 * disk radius) is built
@@ -383,7 +422,8 @@ void host_disk_areas(const HostGeometry &g, const int *bc2, int firstDir, int se
   // rayGeometryDisk.hpp:281-284 indexes the 2-entry BC array by AXIS; axis 2 is
   // out of range there, we use entry 1 for it.
   auto bcAxis = [&](int axis) { return bc2[axis > 1 ? 1 : axis]; };
-  for (uint32_t i = 0; i < n; ++i) {
+  parallel_ranges(n, [&](unsigned, uint32_t rb, uint32_t re) {
+  for (uint32_t i = rb; i < re; ++i) {
     const float *disk = &g.disk4[4 * (size_t)i];
     const float *nrm = &g.normal3[3 * (size_t)i];
     if (g.D == 3) {
@@ -417,6 +457,7 @@ void host_disk_areas(const HostGeometry &g, const int *bc2, int firstDir, int se
       areas[i] = a;
     }
   }
+  });
 }
 
 float host_sort_plane(const HostGeometry &g, int axis, float fallback, float *modeShare) {
@@ -428,7 +469,12 @@ float host_sort_plane(const HostGeometry &g, int axis, float fallback, float *mo
   constexpr int SL = 256;
   std::vector<double> w(SL, 0.0), wh(SL, 0.0);
   const double inv = SL / ((double)hi - (double)lo);
-  for (uint32_t i = 0; i < g.numPrims; ++i) {
+  // per-thread histograms, merged in thread order (the plane only orders work: its last bits
+  // have no influence on any result)
+  std::vector<double> tw((size_t)kMaxHostThreads * SL, 0.0), twh((size_t)kMaxHostThreads * SL, 0.0);
+  parallel_ranges(g.numPrims, [&](unsigned t, uint32_t rb, uint32_t re) {
+  double *w = &tw[(size_t)t * SL], *wh = &twh[(size_t)t * SL];
+  for (uint32_t i = rb; i < re; ++i) {
     double h, a;
     if (g.geo == 0) {
       const float *d = &g.disk4[4 * (size_t)i];
@@ -451,6 +497,12 @@ float host_sort_plane(const HostGeometry &g, int axis, float fallback, float *mo
     w[k] += a;
     wh[k] += a * h;
   }
+  });
+  for (unsigned t = 0; t < kMaxHostThreads; ++t)
+    for (int k = 0; k < SL; ++k) {
+      w[k] += tw[(size_t)t * SL + k];
+      wh[k] += twh[(size_t)t * SL + k];
+    }
   int best = 0;
   double total = w[0];
   for (int k = 1; k < SL; ++k) {
