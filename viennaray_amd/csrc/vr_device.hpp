@@ -125,7 +125,7 @@ __device__ __forceinline__ void rng_resume(Rng &r, unsigned seed, unsigned k, u6
 // cold start: 156 steps of the recurrence to reach s[156]
 __device__ __forceinline__ void rng_init(Rng &r, unsigned seed, u64 *scratchLane) {
   u64 x = seed;
-#pragma unroll 4
+#pragma unroll 39
   for (int j = 1; j <= 156; ++j)
     x = mt_step(x, j);
   rng_resume(r, seed, 0, (u64)seed, x);
@@ -144,7 +144,7 @@ template <int K> __device__ __forceinline__ void mt_first_outputs(unsigned seed,
     x = mt_step(x, j);
     w[j] = x;
   }
-#pragma unroll 4
+#pragma unroll 38 // (152 steps = 4 x 38: the step needs its index as a literal; deeper unrolling loses in the I-cache)
   for (int j = K + 1; j < 156; ++j)
     x = mt_step(x, j);
 #pragma unroll
