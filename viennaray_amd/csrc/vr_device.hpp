@@ -57,13 +57,17 @@ __device__ __forceinline__ void vnormalize(V3 &a) {
 // ---------------------------------------------------------------------------
 typedef unsigned long long u64;
 
+// wave-wide vote as a lane mask.  (HIP's __ballot compares a materialised 0/1 value:
+// v_cndmask + v_cmp per call; the builtin hands the condition mask through.)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 // -DVR_DIAG: lane-occupancy counters.  DIAG(k) inside any (divergent) region counts one
 // wave-level execution and the lanes that took part; summed into counters[16 + 2k, +1].
 #ifdef VR_DIAG
 #define VR_DIAG_DECL unsigned diagW[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, diagL[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define DIAG(k)                                                                                                        \
   do {                                                                                                                 \
-    const unsigned long long m_ = __ballot(1);                                                                         \
+    const unsigned long long m_ = ballot64(1);                                                                         \
     if ((int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1)                                                        \
       ++diagW[k];                                                                                                      \
     ++diagL[k];                                                                                                        \
@@ -390,10 +394,10 @@ __device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, 
     bool parked = false;
     for (;;) {
       const bool search = node < p.numNodes && !parked;
-      const unsigned long long sm = __ballot(search);
+      const unsigned long long sm = ballot64(search);
       if (!sm)
         break;
-      const unsigned long long km = __ballot(parked);
+      const unsigned long long km = ballot64(parked);
       if (100u * (unsigned)__popcll(km) >= p.walkPark * (unsigned)__popcll(km | sm))
         break;
       if (search) {
@@ -405,10 +409,10 @@ __device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, 
         const float ty0 = __builtin_fmaf(ly, inv.y, -oi.y), ty1 = __builtin_fmaf(hy, inv.y, -oi.y);
         const float tz0 = __builtin_fmaf(lz, inv.z, -oi.z), tz1 = __builtin_fmaf(hz, inv.z, -oi.z);
         const float tEntry = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
-        const float tExit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), h.t));
+        const float tExit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
         const unsigned link = nd.w;
         const bool leaf = (link & VR_LEAF) != 0u;
-        const bool hitBox = tEntry <= tExit;
+        const bool hitBox = tEntry <= tExit && tEntry <= h.t;
         if (hitBox && leaf) {
           if (pend == 0u)
             pend = link;
@@ -420,10 +424,10 @@ __device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, 
           node = (hitBox || leaf) ? node + 1u : link;
       }
     }
-    if (__ballot(pend != 0u)) {
+    if (ballot64(pend != 0u)) {
       const unsigned first = pend & VR_LEAF_FIRST_MASK;
       const unsigned cnt = pend ? (pend >> 27) & 15u : 0u;
-      for (unsigned i = 0; __ballot(i < cnt); ++i) {
+      for (unsigned i = 0; ballot64(i < cnt); ++i) {
         if (i < cnt) {
           DIAG(2);
           const unsigned q = first + i;
@@ -443,7 +447,7 @@ __device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, 
       }
       pend = 0u;
     }
-    if ((unsigned)__popcll(__ballot(node < p.numNodes)) < minLanes)
+    if ((unsigned)__popcll(ballot64(node < p.numNodes)) < minLanes)
       break;
   }
 }
@@ -480,7 +484,8 @@ __device__ __forceinline__ bool bvh_hit_packet(const TraceParams &p, bool part, 
                                                HitRec &h, unsigned budget, unsigned ratio VR_DIAG_ARGS) {
   if (p.numPrims == 0)
     return true;
-  const unsigned lanes = (unsigned)__popcll(__ballot(part));
+  const unsigned long long partMask = ballot64(part);
+  const unsigned lanes = (unsigned)__popcll(partMask);
   unsigned wants = 16u * lanes; // start-up allowance: 16 visits
   unsigned visits = 0;
   ConstF4 nodes = (ConstF4)(p.nodes);
@@ -501,10 +506,14 @@ __device__ __forceinline__ bool bvh_hit_packet(const TraceParams &p, bool part, 
     const float ty0 = __builtin_fmaf(q0.y, inv.y, -oi.y), ty1 = __builtin_fmaf(q1.y, inv.y, -oi.y);
     const float tz0 = __builtin_fmaf(q0.z, inv.z, -oi.z), tz1 = __builtin_fmaf(q1.z, inv.z, -oi.z);
     const float tEntry = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
-    const float tExit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), h.t));
+    const float tExit = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
     const unsigned link = __builtin_amdgcn_readfirstlane(__float_as_uint(q0.w));
     const unsigned esc = __builtin_amdgcn_readfirstlane(__float_as_uint(q1.w));
-    const unsigned long long want = __ballot(part && tEntry <= tExit);
+    // (tEntry <= min(tExit, h.t), as two compares: a min with the loop-carried h.t costs a
+    //  canonicalising v_max besides the v_min.
+    //  Votes are taken per comparison and combined as scalar masks: a vote on a combined
+    //  condition is lowered through a materialised 0/1 value, two more VALU per visit.)
+    const unsigned long long want = partMask & ballot64(tEntry <= tExit) & ballot64(tEntry <= h.t);
     wants += (unsigned)__popcll(want);
     if (want) {
       if (link & VR_LEAF) {

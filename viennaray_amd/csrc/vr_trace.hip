@@ -269,7 +269,7 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
 // credit the same accumulator with the same weight are merged into one atomic
 // (sorted rays: a wavefront's hits fall on a handful of disks).
 __device__ __forceinline__ void credit_aggregated(unsigned long long *acc, bool cond, unsigned pos, u64 wfx) {
-  unsigned long long todo = __ballot(cond);
+  unsigned long long todo = ballot64(cond);
   const unsigned lane = threadIdx.x & 63u;
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
@@ -277,7 +277,7 @@ __device__ __forceinline__ void credit_aggregated(unsigned long long *acc, bool 
     const unsigned wlo = __shfl((unsigned)(wfx & 0xFFFFFFFFull), leader, 64);
     const unsigned whi = __shfl((unsigned)(wfx >> 32), leader, 64);
     const u64 W = ((u64)whi << 32) | wlo;
-    const unsigned long long same = __ballot(cond && pos == P && wfx == W);
+    const unsigned long long same = ballot64(cond && pos == P && wfx == W);
     if ((int)lane == leader)
       atomicAdd(&acc[P], W * (u64)__popcll(same));
     todo &= ~same;
@@ -369,7 +369,7 @@ trace_kernel(const TraceParams p) {
     asm volatile("" ::: "memory");
     // ---- wave-wide compaction / restart: idle lanes pull the next sorted rays ----
     for (int rep = 0; rep < 8;) {
-      const unsigned long long idle = __ballot(!active);
+      const unsigned long long idle = ballot64(!active);
       if (!idle)
         break;
       if (curOff >= curCnt) { // current bin used up: next bin of the span, or a new span
@@ -434,7 +434,7 @@ trace_kernel(const TraceParams p) {
       const unsigned nIdle = __popcll(idle);
       curOff += nIdle < avail ? nIdle : avail;
     }
-    if (!__ballot(active))
+    if (!ballot64(active))
       break;
 
     // ---- closest hit of a trace segment (rtcIntersect1, rayTraceKernel.hpp:163-167) ----
@@ -455,10 +455,10 @@ trace_kernel(const TraceParams p) {
       hit_clear(h);
       node = 0u;
     }
-    const unsigned long long carried = CARRY ? __ballot(active && !start) : 0ull;
+    const unsigned long long carried = CARRY ? ballot64(active && !start) : 0ull;
     start = false;
     const bool usePacket =
-        !(p.debugFlags & 32u) && carried == 0ull && packetSkip == 0 && __popcll(__ballot(active)) >= 8;
+        !(p.debugFlags & 32u) && carried == 0ull && packetSkip == 0 && __popcll(ballot64(active)) >= 8;
     bool packetDone = false;
     if (usePacket) {
       packetDone = bvh_hit_packet<GEO>(p, active, org, dir, tnear, h, p.packetBudget, p.packetRatio VR_DIAG_PASS);
@@ -471,7 +471,7 @@ trace_kernel(const TraceParams p) {
       --packetSkip;
     }
     if (!packetDone) {
-      const unsigned walking = (unsigned)__popcll(__ballot(active && node < p.numNodes));
+      const unsigned walking = (unsigned)__popcll(ballot64(active && node < p.numNodes));
       const unsigned minLanes = (!CARRY || exhausted || walking <= p.walkExit) ? 1u : p.walkExit;
       bvh_walk_lanes<GEO>(p, active, org, dir, tnear, h, node, minLanes VR_DIAG_PASS);
     }
@@ -485,10 +485,10 @@ trace_kernel(const TraceParams p) {
     bool aggregate = packetDone;
     {
       const bool cand = fin && h.geom == 1;
-      const unsigned long long cm = __ballot(cand);
+      const unsigned long long cm = ballot64(cand);
       if (!aggregate && cm) {
         const unsigned sample = (unsigned)__shfl((int)h.pos, __ffsll((long long)cm) - 1, 64);
-        const unsigned same = (unsigned)__popcll(__ballot(cand && h.pos == sample));
+        const unsigned same = (unsigned)__popcll(ballot64(cand && h.pos == sample));
         aggregate = 4u * same >= (unsigned)__popcll(cm) && same >= 4u;
       }
     }
