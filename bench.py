@@ -180,6 +180,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "bytes_per_hit_segment": round(b_hit, 1), "bytes_per_other_segment": b_path,
                          "valu_issue_frac": (round(valu_frac, 3) if valu_frac else None),
+                         "measured_fabric_GBs": (round(traffic / (tavg * 1e-3) / 1e9, 1) if traffic else None),
                          "note": "achieved = SURVEY 8(d) algorithmic bytes / trace_kernel time; sorted rays fetch nodes and "
                                  "disks wave-uniformly through the scalar cache, so measured fabric traffic is far below "
                                  "the algorithmic bytes and frac can exceed 1: the kernel is VALU-issue bound (DESIGN.md 7)"},
