@@ -169,6 +169,28 @@ public:
 };
 
 // ---- particles --------------------------------------------------------------------
+// rayUtil.hpp:49-63.  The built-in particles log nothing; the type is here so programs that
+// pass a DataLog around keep compiling.
+template <class NumericType> struct DataLog {
+  std::vector<std::vector<NumericType>> data;
+  void merge(DataLog<NumericType> &pOther) {
+    for (std::size_t i = 0; i < data.size() && i < pOther.data.size(); i++)
+      for (std::size_t j = 0; j < data[i].size() && j < pOther.data[i].size(); j++)
+        data[i][j] += pOther.data[i][j];
+  }
+};
+
+// raySource.hpp:10-19.  A user-defined source is a host callback per ray and cannot run in
+// the generator kernel: Trace::setSource() records the request and
+// apply() then reports an error instead of silently tracing something else.
+template <typename NumericType> class Source {
+public:
+  virtual ~Source() = default;
+  [[nodiscard]] virtual size_t getNumPoints() const = 0;
+  virtual NumericType getSourceArea() const = 0;
+  virtual NumericType getInitialRayWeight(const size_t) const { return 1.; }
+};
+
 template <typename NumericType> class AbstractParticle {
 public:
   virtual ~AbstractParticle() = default;
@@ -232,6 +254,12 @@ public:
 
   /// Run the ray tracer
   virtual void apply() {
+    if (pSource_) {
+      RTInfo_.error = true;
+      std::cerr << "viennaray_amd: user-defined sources are not supported on the device path "
+                   "(call resetSource() to use the built-in power-cosine source).\n";
+      return;
+    }
     if (!ctx_ || pParticle_ == nullptr) {
       RTInfo_.error = true;
       std::cerr << "No particle was specified in rayTrace. Aborting.\n";
@@ -322,6 +350,9 @@ public:
     if (ctx_)
       vr_set_rng_seed(ctx_, seed);
   }
+  // rayTrace.hpp:58-67
+  void setSource(std::shared_ptr<Source<NumericType>> source) { pSource_ = std::move(source); }
+  void resetSource() { pSource_.reset(); }
   void enableProgressBar() {}
   void disableProgressBar() {}
 
@@ -333,7 +364,12 @@ public:
   }
 
   [[nodiscard]] TracingData<NumericType> &getLocalData() { return localData_; }
+  // rayTrace.hpp:137-145: global data is a borrowed pointer handed to user particles; the
+  // built-in particles never read it
+  [[nodiscard]] TracingData<NumericType> *getGlobalData() { return pGlobalData_; }
+  void setGlobalData(TracingData<NumericType> &data) { pGlobalData_ = &data; }
   [[nodiscard]] TraceInfo getRayTraceInfo() const { return RTInfo_; }
+  [[nodiscard]] DataLog<NumericType> &getDataLog() { return dataLog_; }
   /// the underlying C-ABI context (multi-GPU drivers use vr_set_ray_range etc.)
   [[nodiscard]] vr_context *getContext() { return ctx_; }
 
@@ -362,6 +398,9 @@ protected:
   vr_context *ctx_ = nullptr;
   std::unique_ptr<AbstractParticle<NumericType>> pParticle_ = nullptr;
   TracingData<NumericType> localData_;
+  TracingData<NumericType> *pGlobalData_ = nullptr;
+  DataLog<NumericType> dataLog_;
+  std::shared_ptr<Source<NumericType>> pSource_;
   TraceInfo RTInfo_;
 };
 
