@@ -865,10 +865,10 @@ int vr_apply_prepare(vr_context *c) {
   p.packetBudget = 128;
   if (const char *e = std::getenv("VR_PACKET_BUDGET"))
     p.packetBudget = (uint32_t)std::max(0, std::atoi(e));
-  p.walkPark = 34;
+  p.walkPark = 25;
   if (const char *e = std::getenv("VR_WALK_PARK"))
     p.walkPark = (uint32_t)std::min(100, std::max(1, std::atoi(e)));
-  p.walkExit = 24;
+  p.walkExit = 20;
   if (const char *e = std::getenv("VR_WALK_EXIT"))
     p.walkExit = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   p.packetRatio = 3;
