@@ -40,6 +40,27 @@ def algorithmic_bytes(n_prims, geo_hits, segments, k_neigh=8, h_credit=2.356):
     return geo_hits * hit + (segments - geo_hits) * path, hit, path
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota
+    (a GPU box exposes all 256 hardware threads but grants a 16-CPU quota; 128 OpenMP threads
+    under that quota only throttle each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(pts, nrm, grid_delta, sticking, seed, sample_rays, total_rays):
     """The CPU oracle (restated reference loop, std::mt19937_64 per ray like the
     reference) timed on this box's host cores on a bounded sample of the same
@@ -55,12 +76,12 @@ def cpu_baseline(pts, nrm, grid_delta, sticking, seed, sample_rays, total_rays):
     o.set_num_rays_fixed(total_rays)
     o.set_ray_range(0, sample_rays)
     o.set_rng_seed(seed)
-    cores = po.max_threads()
+    cores = min(po.max_threads(), host_cpu_share())
     o.apply(cores)
     info = o.info()
     return o, dict(value=sample_rays / info["time"] / 1e6, unit="Mrays/s", cores=cores, kind="port",
-                   sample=f"first {sample_rays} rays of the same {total_rays}-ray C2 workload, all host threads "
-                          f"(OpenMP guided,64), oracle setup {t_setup:.1f}s excluded",
+                   sample=f"first {sample_rays} rays of the same {total_rays}-ray C2 workload, one thread per CPU "
+                          f"of this process's share ({cores}; OpenMP guided,64), oracle setup {t_setup:.1f}s excluded",
                    seconds=info["time"])
 
 
