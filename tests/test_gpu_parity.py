@@ -625,3 +625,102 @@ def test_device_bvh_is_consistent_after_every_rebuild():
     m.setParticleType(vr.DiffuseParticle(1.0, "flux"))
     m.applyPrepare()
     assert m.debugBvhCheck() == 0
+
+
+# ---------------------------------------------------------------------------
+# randomised differential test: random scenes / settings, HIP path vs oracle
+# ---------------------------------------------------------------------------
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    D = int(rng.choice([2, 3], p=[0.3, 0.7]))
+    n = int(rng.integers(3, 400))
+    gd = float(rng.choice([0.25, 0.5, 1.0]))
+    span = gd * max(2.0, np.sqrt(n))
+    pts = rng.uniform(-span, span, size=(n, 3)).astype(np.float32)
+    # a rough surface facing the source on average, with some disks turned away
+    nrm = rng.normal(size=(n, 3)).astype(np.float32)
+    if D == 2:
+        pts[:, 2] = 0
+        nrm[:, 2] = 0
+        direction = TD(int(rng.choice([int(TD.POS_Y), int(TD.NEG_Y), int(TD.POS_X), int(TD.NEG_X)])))
+    else:
+        direction = TD(int(rng.integers(0, 6)))
+    axis = {TD.POS_X: 0, TD.NEG_X: 0, TD.POS_Y: 1, TD.NEG_Y: 1, TD.POS_Z: 2, TD.NEG_Z: 2}[direction]
+    sign = 1.0 if direction in (TD.POS_X, TD.POS_Y, TD.POS_Z) else -1.0
+    nrm[:, axis] = sign * (np.abs(nrm[:, axis]) + 0.5)
+    flip = rng.random(n) < 0.1
+    nrm[flip] *= -1
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    bcs = [BC(int(b)) for b in rng.integers(0, 3, size=3)]
+    if rng.random() < 0.5:
+        particle = ("diffuse", float(rng.choice([1.0, 0.5, 0.1, 0.02])), 1.0)
+    else:
+        particle = ("specular", float(rng.choice([1.0, 0.6, 0.2])), float(rng.choice([1.0, 8.0, 100.0])))
+    radius = 0.0 if rng.random() < 0.7 else gd * float(rng.uniform(0.3, 1.2))
+    return dict(D=D, pts=pts, nrm=nrm.astype(np.float32), gd=gd, direction=direction, bcs=bcs[:D] if D == 2 else bcs,
+                particle=particle, radius=radius, rays=int(rng.integers(1, 40)), seed=int(rng.integers(0, 2**31)),
+                max_refl=int(rng.choice([2**32 - 1, 50, 3])), max_bh=int(rng.choice([1000, 5, 0])))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_scenes_match_oracle(seed):
+    c = _random_case(1000 + seed)
+    t, o = make_pair_disks(c["pts"], c["nrm"], c["gd"], c["D"], c["bcs"], c["direction"], c["particle"],
+                           rays_pp=c["rays"], seed=c["seed"], radius=c["radius"])
+    t.setMaxReflections(c["max_refl"])
+    o.set_max_reflections(c["max_refl"])
+    t.setMaxBoundaryHits(c["max_bh"])
+    o.set_max_boundary_hits(c["max_bh"])
+    t.apply()
+    o.apply(4)
+    gi, oi = info_dict(t), o.info()
+    assert gi == {k: oi[k] for k in INFO_KEYS}, c["particle"]
+    f, r = t.getLocalData().getVectorData(0), o.flux()
+    assert l2_rel(f, r) <= 5e-6
+    a, b = t.getDiskAreas(), o.disk_areas()  # two independent restatements of the intersector
+    assert (np.isnan(a) == np.isnan(b)).all()
+    ok = ~np.isnan(b)
+    assert np.allclose(a[ok], b[ok], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_triangle_surfaces_match_oracle(seed):
+    """random rough height fields as triangle meshes, random walls / particle / limits"""
+    rng = np.random.default_rng(5000 + seed)
+    m = int(rng.integers(2, 14))
+    gd = float(rng.choice([0.5, 1.0]))
+    xs, ys = np.meshgrid(np.arange(m) * gd, np.arange(m) * gd, indexing="ij")
+    z = rng.normal(scale=float(rng.choice([0.0, 0.3, 2.0])) * gd, size=(m, m))
+    v = np.stack([xs.ravel(), ys.ravel(), z.ravel()], 1).astype(np.float32)
+    tri = []
+    for i in range(m - 1):
+        for j in range(m - 1):
+            a, b, c, d = i * m + j, (i + 1) * m + j, (i + 1) * m + j + 1, i * m + j + 1
+            tri += [[a, b, c], [a, c, d]] if rng.random() < 0.5 else [[a, b, d], [b, c, d]]
+    tri = np.array(tri, dtype=np.uint32)
+    bcs = [BC(int(b)) for b in rng.integers(0, 3, size=3)]
+    t = vr.TraceTriangle(3)
+    t.setGeometry(v, tri, gd)
+    t.setBoundaryConditions(bcs)
+    o = po.Oracle()
+    o.set_triangles(v, tri, gd, 3)
+    o.set_boundary_conditions([int(b) for b in bcs])
+    if rng.random() < 0.5:
+        st = float(rng.choice([1.0, 0.3, 0.05]))
+        t.setParticleType(vr.DiffuseParticle(st, "flux"))
+        o.set_particle(po.DIFFUSE, st)
+    else:
+        st, pw = float(rng.choice([1.0, 0.4])), float(rng.choice([1.0, 30.0]))
+        t.setParticleType(vr.SpecularParticle(st, pw, "flux"))
+        o.set_particle(po.SPECULAR, st, pw)
+    rays, sd = int(rng.integers(1, 60)), int(rng.integers(0, 2**31))
+    t.setNumberOfRaysPerPoint(rays)
+    o.set_num_rays_per_point(rays)
+    t.setRngSeed(sd)
+    o.set_rng_seed(sd)
+    o.set_lazy_rng(True)
+    t.apply()
+    o.apply(4)
+    gi, oi = info_dict(t), o.info()
+    assert gi == {k: oi[k] for k in INFO_KEYS}
+    assert l2_rel(t.getLocalData().getVectorData(0), o.flux()) <= 5e-6
