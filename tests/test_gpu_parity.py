@@ -657,7 +657,12 @@ def _random_case(seed):
     else:
         particle = ("specular", float(rng.choice([1.0, 0.6, 0.2])), float(rng.choice([1.0, 8.0, 100.0])))
     radius = 0.0 if rng.random() < 0.7 else gd * float(rng.uniform(0.3, 1.2))
-    return dict(D=D, pts=pts, nrm=nrm.astype(np.float32), gd=gd, direction=direction, bcs=bcs[:D] if D == 2 else bcs,
+    primary = None
+    if D == 3 and rng.random() < 0.3:  # tilted source: rejection loop in the generator
+        primary = rng.normal(scale=0.4, size=3)
+        primary[axis] = -sign
+        primary = (primary / np.linalg.norm(primary)).astype(np.float32)
+    return dict(primary=primary, D=D, pts=pts, nrm=nrm.astype(np.float32), gd=gd, direction=direction, bcs=bcs[:D] if D == 2 else bcs,
                 particle=particle, radius=radius, rays=int(rng.integers(1, 40)), seed=int(rng.integers(0, 2**31)),
                 max_refl=int(rng.choice([2**32 - 1, 50, 3])), max_bh=int(rng.choice([1000, 5, 0])))
 
@@ -666,7 +671,7 @@ def _random_case(seed):
 def test_random_scenes_match_oracle(seed):
     c = _random_case(1000 + seed)
     t, o = make_pair_disks(c["pts"], c["nrm"], c["gd"], c["D"], c["bcs"], c["direction"], c["particle"],
-                           rays_pp=c["rays"], seed=c["seed"], radius=c["radius"])
+                           rays_pp=c["rays"], seed=c["seed"], radius=c["radius"], primary=c["primary"])
     t.setMaxReflections(c["max_refl"])
     o.set_max_reflections(c["max_refl"])
     t.setMaxBoundaryHits(c["max_bh"])
