@@ -131,41 +131,108 @@ inline TriangleMesh convertLinesToTriangles(const LineMesh &lineMesh) {
   return mesh;
 }
 
-// ---- TracingData (vector data part) ------------------------------------------------
+// ---- TracingData (rayTracingData.hpp:16-219) ---------------------------------------------
+// Labelled per-primitive vectors and labelled scalars with a merge type each.  The device
+// path fills vector 0 of Trace::getLocalData() (merge type SUM); everything else is a plain
+// container for the caller, with the reference's method names and defaults.
 template <typename NumericType> class TracingData {
-  std::vector<std::vector<NumericType>> vectorData_;
-  std::vector<std::string> vectorDataLabels_;
-  std::vector<TracingDataMergeEnum> vectorDataMerge_;
+  std::vector<NumericType> scalars_;
+  std::vector<std::vector<NumericType>> vectors_;
+  std::vector<std::string> scalarLabels_, vectorLabels_;
+  std::vector<TracingDataMergeEnum> scalarMerge_, vectorMerge_;
 
-public:
-  void setNumberOfVectorData(int size) {
-    vectorData_.clear();
-    vectorData_.resize(size);
-    vectorDataMerge_.resize(size, TracingDataMergeEnum::SUM);
-    vectorDataLabels_.resize(size, "vectorData");
-  }
-  void setVectorData(int num, std::vector<NumericType> &&v, std::string label = "vectorData") {
-    vectorData_[num] = std::move(v);
-    vectorDataLabels_[num] = std::move(label);
-  }
-  void setVectorData(int num, size_t size, NumericType value, std::string label = "vectorData") {
-    vectorData_[num].assign(size, value);
-    vectorDataLabels_[num] = std::move(label);
-  }
-  [[nodiscard]] std::vector<NumericType> &getVectorData(int i) { return vectorData_[i]; }
-  [[nodiscard]] std::vector<NumericType> &getVectorData(const std::string &label) {
-    return vectorData_[getVectorDataIndex(label)];
-  }
-  [[nodiscard]] std::vector<std::vector<NumericType>> &getVectorData() { return vectorData_; }
-  [[nodiscard]] std::string getVectorDataLabel(int i) const { return vectorDataLabels_[i]; }
-  [[nodiscard]] int getVectorDataIndex(const std::string &label) const {
-    for (int i = 0; i < (int)vectorDataLabels_.size(); ++i)
-      if (vectorDataLabels_[i] == label)
+  static int find(const std::vector<std::string> &labels, const std::string &label, const char *what) {
+    for (int i = 0; i < (int)labels.size(); ++i)
+      if (labels[i] == label)
         return i;
-    std::cerr << "Can not find vector data label in TracingData.\n";
+    std::cerr << "Can not find " << what << " data label in TracingData.\n";
     return -1;
   }
-  [[nodiscard]] TracingDataMergeEnum getVectorMergeType(int num) const { return vectorDataMerge_[num]; }
+
+public:
+  TracingData() = default;
+  TracingData(const TracingData &) = default;
+  TracingData &operator=(const TracingData &) = default;
+  // a moved-from object is left EMPTY (the reference's test checks data() == nullptr)
+  TracingData(TracingData &&o) noexcept { *this = std::move(o); }
+  TracingData &operator=(TracingData &&o) noexcept {
+    scalars_ = std::exchange(o.scalars_, {});
+    vectors_ = std::exchange(o.vectors_, {});
+    scalarLabels_ = std::exchange(o.scalarLabels_, {});
+    vectorLabels_ = std::exchange(o.vectorLabels_, {});
+    scalarMerge_ = std::exchange(o.scalarMerge_, {});
+    vectorMerge_ = std::exchange(o.vectorMerge_, {});
+    return *this;
+  }
+
+  void setNumberOfVectorData(int size) {
+    vectors_.clear();
+    vectors_.resize(size);
+    vectorMerge_.resize(size, TracingDataMergeEnum::SUM);
+    vectorLabels_.resize(size, "vectorData");
+  }
+  void setNumberOfScalarData(int size) {
+    scalars_.clear();
+    scalars_.resize(size);
+    scalarMerge_.resize(size, TracingDataMergeEnum::SUM);
+    scalarLabels_.resize(size, "scalarData");
+  }
+  void setScalarData(int num, NumericType value, std::string label = "scalarData") {
+    scalars_[num] = value;
+    scalarLabels_[num] = std::move(label);
+  }
+  void setVectorData(int num, std::vector<NumericType> &v, std::string label = "vectorData") {
+    vectors_[num] = v;
+    vectorLabels_[num] = std::move(label);
+  }
+  void setVectorData(int num, std::vector<NumericType> &&v, std::string label = "vectorData") {
+    vectors_[num] = std::move(v);
+    vectorLabels_[num] = std::move(label);
+  }
+  void setVectorData(int num, size_t size, NumericType value, std::string label = "vectorData") {
+    vectors_[num].assign(size, value);
+    vectorLabels_[num] = std::move(label);
+  }
+  void setVectorData(int num, NumericType value, std::string label = "vectorData") {
+    vectors_[num].assign(vectors_[num].size(), value);
+    vectorLabels_[num] = std::move(label);
+  }
+  void appendVectorData(int num, const std::vector<NumericType> &v) {
+    vectors_[num].insert(vectors_[num].end(), v.begin(), v.end());
+  }
+  void resizeAllVectorData(size_t size, NumericType val = 0) {
+    for (auto &v : vectors_) {
+      v.clear();
+      v.resize(size, val);
+    }
+  }
+  void setVectorMergeType(const std::vector<TracingDataMergeEnum> &m) { vectorMerge_ = m; }
+  void setVectorMergeType(int num, TracingDataMergeEnum m) { vectorMerge_[num] = m; }
+  void setScalarMergeType(const std::vector<TracingDataMergeEnum> &m) { scalarMerge_ = m; }
+  void setScalarMergeType(int num, TracingDataMergeEnum m) { scalarMerge_[num] = m; }
+
+  [[nodiscard]] std::vector<NumericType> &getVectorData(int i) { return vectors_[i]; }
+  [[nodiscard]] const std::vector<NumericType> &getVectorData(int i) const { return vectors_[i]; }
+  [[nodiscard]] std::vector<NumericType> &getVectorData(const std::string &label) {
+    return vectors_[getVectorDataIndex(label)];
+  }
+  [[nodiscard]] std::vector<std::vector<NumericType>> &getVectorData() { return vectors_; }
+  [[nodiscard]] const std::vector<std::vector<NumericType>> &getVectorData() const { return vectors_; }
+  [[nodiscard]] NumericType &getScalarData(int i) { return scalars_[i]; }
+  [[nodiscard]] const NumericType &getScalarData(int i) const { return scalars_[i]; }
+  [[nodiscard]] NumericType &getScalarData(const std::string &label) { return scalars_[getScalarDataIndex(label)]; }
+  [[nodiscard]] std::vector<NumericType> &getScalarData() { return scalars_; }
+  [[nodiscard]] const std::vector<NumericType> &getScalarData() const { return scalars_; }
+  [[nodiscard]] std::string getVectorDataLabel(int i) const {
+    return i < (int)vectorLabels_.size() ? vectorLabels_[i] : std::string();
+  }
+  [[nodiscard]] std::string getScalarDataLabel(int i) const {
+    return i < (int)scalarLabels_.size() ? scalarLabels_[i] : std::string();
+  }
+  [[nodiscard]] int getVectorDataIndex(const std::string &label) const { return find(vectorLabels_, label, "vector"); }
+  [[nodiscard]] int getScalarDataIndex(const std::string &label) const { return find(scalarLabels_, label, "scalar"); }
+  [[nodiscard]] TracingDataMergeEnum getVectorMergeType(int num) const { return vectorMerge_[num]; }
+  [[nodiscard]] TracingDataMergeEnum getScalarMergeType(int num) const { return scalarMerge_[num]; }
 };
 
 // ---- particles --------------------------------------------------------------------

@@ -78,33 +78,79 @@ class SpecularParticle:
 
 
 class TracingData:
-    """Minimal rayTracingData.hpp:16-219: labelled vectors (merge type SUM)."""
+    """rayTracingData.hpp:16-219: labelled vectors and scalars with a merge type each.  The
+    device path fills vector 0 of Trace.getLocalData() (merge type SUM)."""
 
     def __init__(self):
-        self._vectors = []
-        self._labels = []
+        self._vectors, self._vlabels, self._vmerge = [], [], []
+        self._scalars, self._slabels, self._smerge = [], [], []
 
     def setNumberOfVectorData(self, n):
         self._vectors = [np.zeros(0, dtype=np.float32) for _ in range(n)]
-        self._labels = ["vectorData"] * n
+        self._vlabels = ["vectorData"] * n
+        self._vmerge = [TracingDataMergeEnum.SUM] * n
 
-    def setVectorData(self, num, data, label="vectorData"):
+    def setNumberOfScalarData(self, n):
+        self._scalars = [0.0] * n
+        self._slabels = ["scalarData"] * n
+        self._smerge = [TracingDataMergeEnum.SUM] * n
+
+    def setScalarData(self, num, value, label="scalarData"):
+        self._scalars[num] = float(value)
+        self._slabels[num] = label
+
+    def setVectorData(self, num, data, label="vectorData", value=None):
+        """setVectorData(num, array, label) or setVectorData(num, size, label, value=v)"""
+        if value is not None:
+            data = np.full(int(data), value, dtype=np.float32)
         self._vectors[num] = np.asarray(data, dtype=np.float32)
-        self._labels[num] = label
+        self._vlabels[num] = label
+
+    def appendVectorData(self, num, data):
+        self._vectors[num] = np.concatenate([self._vectors[num], np.asarray(data, dtype=np.float32)])
+
+    def resizeAllVectorData(self, size, val=0.0):
+        self._vectors = [np.full(int(size), val, dtype=np.float32) for _ in self._vectors]
+
+    def setVectorMergeType(self, num, m):
+        self._vmerge[num] = TracingDataMergeEnum(m)
+
+    def setScalarMergeType(self, num, m):
+        self._smerge[num] = TracingDataMergeEnum(m)
 
     def getVectorData(self, key=0):
         if isinstance(key, str):
-            key = self.getVectorDataIndex(key)
+            i = self.getVectorDataIndex(key)
+            if i < 0:
+                raise KeyError("Can not find vector data label in TracingData.")
+            key = i
         return self._vectors[key]
 
+    def getScalarData(self, key=0):
+        if isinstance(key, str):
+            i = self.getScalarDataIndex(key)
+            if i < 0:
+                raise KeyError("Can not find scalar data label in TracingData.")
+            key = i
+        return self._scalars[key]
+
     def getVectorDataLabel(self, i):
-        return self._labels[i]
+        return self._vlabels[i] if i < len(self._vlabels) else ""
+
+    def getScalarDataLabel(self, i):
+        return self._slabels[i] if i < len(self._slabels) else ""
 
     def getVectorDataIndex(self, label):
-        for i, l in enumerate(self._labels):
-            if l == label:
-                return i
-        raise KeyError("Can not find vector data label in TracingData.")
+        return self._vlabels.index(label) if label in self._vlabels else -1
+
+    def getScalarDataIndex(self, label):
+        return self._slabels.index(label) if label in self._slabels else -1
+
+    def getVectorMergeType(self, num):
+        return self._vmerge[num]
+
+    def getScalarMergeType(self, num):
+        return self._smerge[num]
 
 
 def _fptr(a):
