@@ -42,6 +42,61 @@ template <class T, size_t D> using VectorType = std::array<T, D>;
 template <class T> using Vec2D = std::array<T, 2>;
 template <class T> using Vec3D = std::array<T, 3>;
 using Vec3Df = Vec3D<float>;
+using Vec3Dd = Vec3D<double>;
+
+// The handful of ViennaCore vector helpers (vcVectorType.hpp) that ViennaRay programs use on
+// their points and normals, so that such a program builds without ViennaCore.  Plain
+// component loops; known answers: the reference's tests/utilFuncs (tests/aux/facade_units.cpp).
+template <class T, size_t D> VectorType<T, D> operator+(const VectorType<T, D> &a, const VectorType<T, D> &b) {
+  VectorType<T, D> r;
+  for (size_t i = 0; i < D; ++i)
+    r[i] = a[i] + b[i];
+  return r;
+}
+template <class T, size_t D> VectorType<T, D> operator-(const VectorType<T, D> &a, const VectorType<T, D> &b) {
+  VectorType<T, D> r;
+  for (size_t i = 0; i < D; ++i)
+    r[i] = a[i] - b[i];
+  return r;
+}
+template <class T, size_t D> VectorType<T, D> operator*(const T &f, const VectorType<T, D> &a) {
+  VectorType<T, D> r;
+  for (size_t i = 0; i < D; ++i)
+    r[i] = f * a[i];
+  return r;
+}
+template <class T, size_t D> VectorType<T, D> operator*(const VectorType<T, D> &a, const T &f) { return f * a; }
+template <class T, size_t D>
+VectorType<T, D> Sum(const VectorType<T, D> &a, const VectorType<T, D> &b, const VectorType<T, D> &c) {
+  return a + b + c;
+}
+template <class T, size_t D> T DotProduct(const VectorType<T, D> &a, const VectorType<T, D> &b) {
+  T s = 0;
+  for (size_t i = 0; i < D; ++i)
+    s += a[i] * b[i];
+  return s;
+}
+template <class T> Vec3D<T> CrossProduct(const Vec3D<T> &a, const Vec3D<T> &b) {
+  return Vec3D<T>{a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+}
+template <class T, size_t D> T Norm2(const VectorType<T, D> &a) { return DotProduct(a, a); }
+template <class T, size_t D> T Norm(const VectorType<T, D> &a) { return std::sqrt(Norm2(a)); }
+template <class T, size_t D> void Normalize(VectorType<T, D> &a) {
+  const T n = Norm(a);
+  if (n > T(0))
+    for (size_t i = 0; i < D; ++i)
+      a[i] /= n;
+}
+template <class T, size_t D> bool IsNormalized(const VectorType<T, D> &a) {
+  return std::fabs(Norm(a) - T(1)) < T(1e-4);
+}
+template <class T, size_t D> T Distance(const VectorType<T, D> &a, const VectorType<T, D> &b) { return Norm(a - b); }
+template <class T, size_t D> VectorType<T, D> Inv(const VectorType<T, D> &a) { return T(-1) * a; }
+template <class T, size_t D>
+VectorType<T, D> ScaleAdd(const VectorType<T, D> &a, const VectorType<T, D> &b, const T &f) { // a * f + b
+  return f * a + b;
+}
+template <class T> Vec3D<T> ComputeNormal(const Vec3D<Vec3D<T>> &p) { return CrossProduct(p[1] - p[0], p[2] - p[0]); }
 
 struct Timer {
   std::chrono::steady_clock::time_point t0;

@@ -5,6 +5,8 @@
 #include <rayTracingData.hpp>
 #include <rayUtil.hpp>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -52,6 +54,34 @@ int main(int argc, char **argv) {
     CHECK(q->getLocalDataLabels().size() == 1 && q->getLocalDataLabels()[0] == "test");
     auto c = q->clone();
     CHECK(c->getSourceDistributionPower() == 50.);
+  }
+  { // tests/utilFuncs/utilFuncs.cpp:10-86 (the ViennaCore vector helpers ViennaRay programs use)
+    const float eps = 1e-6f;
+    auto close = [&](float a, double b) { return std::fabs((double)a - b) <= eps * std::max(1.0, std::fabs(b)); };
+    Vec3D<float> v1{1.2f, 2.4f, 3.6f}, v2{2.8f, 3.6f, 4.4f}, v3{1.f, 1.f, 1.f};
+    auto r = v1 + v2;
+    CHECK(close(r[0], 4.) && close(r[1], 6.) && close(r[2], 8.));
+    r = Sum(v1, v2, v3);
+    CHECK(close(r[0], 5.) && close(r[1], 7.) && close(r[2], 9.));
+    r = v1 - v3;
+    CHECK(close(r[0], 0.2) && close(r[1], 1.4) && close(r[2], 2.6));
+    Vec3D<float> a{1.f, 0.f, 1.f}, b{1.f, 0.f, 0.f};
+    CHECK(close(DotProduct(a, b), 1.));
+    auto cp = CrossProduct(a, b);
+    CHECK(close(cp[0], 0.) && close(cp[1], 1.) && close(cp[2], 0.));
+    Vec3D<float> n1{1.f, 1.f, 1.f};
+    CHECK(std::fabs(Norm(n1) - 1.73205f) < 1e-5f);
+    Normalize(n1);
+    CHECK(close(Norm(n1), 1.) && IsNormalized(n1));
+    Vec3D<float> d1{1.f, 1.f, 1.f}, d2{2.f, 1.f, 1.f};
+    CHECK(close(Distance(d1, d2), 1.));
+    d1 = 2.f * d1;
+    CHECK(close(d1[0], 2.) && close(d1[1], 2.) && close(d1[2], 2.));
+    auto inv = Inv(d1);
+    CHECK(close(inv[0], -2.) && close(inv[1], -2.) && close(inv[2], -2.));
+    Vec3D<Vec3D<float>> coords{Vec3D<float>{0.f, 0.f, 0.f}, Vec3D<float>{1.f, 0.f, 1.f}, Vec3D<float>{1.f, 0.f, 0.f}};
+    auto nn = ComputeNormal(coords);
+    CHECK(close(nn[0], 0.) && close(nn[1], 1.) && close(nn[2], 0.));
   }
   if (argc > 1) { // tests/linesToTriangles + rayMesh.hpp:27-80,133-175 on lineMesh.dat
     std::vector<Vec3D<float>> points;
