@@ -121,9 +121,8 @@ struct vr_context {
   bool hostNeighborsValid = false;
   // ray stream (one batch)
   DevBuf<float> dSlotRec, dSlotRec2, dWalls;
-  DevBuf<unsigned long long> dSlotTape, dSlotTape2;
   DevBuf<uint32_t> dBinCount, dBinCount2;
-  size_t slotStride = 0;
+  size_t slotStride = 0; // record slots of the ray-stream buffer (bins + overflow region)
   uint32_t raysPerBin = 32;
   std::vector<hipEvent_t> evSort, evTraced; // per batch: sorted stream ready / trace finished
   bool overlap = false;
@@ -215,8 +214,6 @@ void vr_destroy(vr_context *c) {
   c->dWalls.release();
   c->dSlotRec.release();
   c->dSlotRec2.release();
-  c->dSlotTape.release();
-  c->dSlotTape2.release();
   c->dBinCount.release();
   c->dBinCount2.release();
   c->dScanTmp.release();
@@ -816,12 +813,10 @@ int vr_apply_prepare(vr_context *c) {
   p.workCounter = c->dCounters.p + 8;
   p.rngScratch = c->dScratch.p;
   p.slotRec = c->dSlotRec.p;
-  p.slotTape = c->absorb ? nullptr : c->dSlotTape.p;
   p.binCount = c->dBinCount.p;
   p.idxList = nullptr;
   p.batchFirst = first;
   p.batchCount = 0;
-  p.slotStride = (uint32_t)c->slotStride;
   p.ovCap = c->batchCap;
   p.numBins = c->numBins;
   p.seed = seed;
@@ -918,11 +913,10 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
     const uint64_t waves = std::min<uint64_t>(c->grid, ((uint64_t)count + 255) / 256) * (VR_BLOCK / 64);
     p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, nbBatch / std::max<uint64_t>(waves * 2, 1)));
   }
-  const bool tape = !c->absorb;
+  const bool keepRng = !c->absorb; // records carry the RNG cursors
   const unsigned slot = c->overlap ? (unsigned)(batchNo & 1) : 0u;
   if (slot) {
     p.slotRec = c->dSlotRec2.p;
-    p.slotTape = tape ? c->dSlotTape2.p : nullptr;
     p.binCount = c->dBinCount2.p;
   }
   p.workCounter = c->dCounters.p + 8 + slot;
@@ -943,7 +937,7 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   if (c->overlap && batchNo >= 2)
     VR_HIP(c, hipStreamWaitEvent(sg, c->evTraced[batchNo - 2], 0));
   VR_HIP(c, hipMemsetAsync(p.binCount, 0, ((size_t)p.numBins + 1) * 4, sg));
-  VR_HIP(c, launch_gen(p, c->geo.D, tape, (unsigned)c->numCUs * 8u, sg));
+  VR_HIP(c, launch_gen(p, c->geo.D, keepRng, (unsigned)c->numCUs * 8u, sg));
   // tracer
   if (c->overlap) {
     VR_HIP(c, hipEventRecord(c->evSort[batchNo], sg));

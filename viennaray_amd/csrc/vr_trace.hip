@@ -180,7 +180,7 @@ template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_basi
 }
 
 // ---------------------------------------------------------------------------
-// exclusive scan of the histogram (in place), 2048 elements per block
+// exclusive scan (in place), 2048 elements per block: radix-sort digit tables, neighbour offsets
 // ---------------------------------------------------------------------------
 constexpr unsigned SCAN_PER_THREAD = 8;
 constexpr unsigned SCAN_PER_BLOCK = SCAN_PER_THREAD * VR_BLOCK;

@@ -53,14 +53,12 @@ struct TraceParams {
   unsigned long long *rngScratch; // [waves][312][64]
   // ray stream of the current batch: VR_BIN_CAP record slots per sort bin, then the
   // overflow region (rays whose bin was full), all in one array of 32-byte records
-  float *slotRec;                 // [(numBins * binCap + ovCap)] records of 32 B (+ 64 B tape)
-  unsigned long long *slotTape;   // unused (the tape lives in the record)
+  float *slotRec;                 // [(numBins * binCap + ovCap)] records of 32 B (48 B with the RNG cursors)
   uint32_t *binCount;             // [numBins + 1]; [numBins] counts the overflow rays
                                   // (nullptr: diagnostics, record i goes to slot i)
   const unsigned long long *idxList; // diagnostics: explicit ray indices (or nullptr)
   uint64_t batchFirst;            // global ray index of the batch's ray 0
   uint32_t batchCount;            // rays in this batch
-  uint32_t slotStride;            // slots per tape plane (= total record slots)
   uint32_t ovCap;                 // capacity of the overflow region
   uint32_t binCap;                // record slots per sort bin
   uint32_t numBins;
