@@ -112,6 +112,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL builds its communicator and channels on first use: do that before anything is timed,
+        # whatever --warmup says (an 8 MB int64 buffer like the flux accumulators, and a tiny one)
+        _w = torch.zeros(1 << 20, dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(_w)
+        dist.all_reduce(_w[:8])
+        torch.cuda.synchronize()
+        del _w
 
     # ---- workload C2: P(n) plane, DiffuseParticle, PERIODIC, cosine source ----
     n = args.grid
