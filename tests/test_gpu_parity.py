@@ -729,3 +729,22 @@ def test_random_triangle_surfaces_match_oracle(seed):
     gi, oi = info_dict(t), o.info()
     assert gi == {k: oi[k] for k in INFO_KEYS}
     assert l2_rel(t.getLocalData().getVectorData(0), o.flux()) <= 5e-6
+
+
+@pytest.mark.parametrize("geom", ["trench3d", "sphere", "trench2d"])
+def test_device_smoothing_matches_host_and_oracle(geom, monkeypatch):
+    """smoothFlux(flux, 1) runs on the device neighbourhood; it sums the neighbours in ascending
+    original id like the host path and the oracle, so all three agree bit for bit."""
+    gd, p, n = {"sphere": sphere3d, "trench3d": trench3d, "trench2d": trench2d}[geom]()
+    D = 2 if geom == "trench2d" else 3
+    direction = TD.POS_Y if D == 2 else TD.POS_Z
+    t, o = make_pair_disks(p, n, gd, D, [BC.REFLECTIVE_BOUNDARY] * D, direction, ("diffuse", 0.3, 1), rays_pp=50)
+    t.apply()
+    o.apply(4)
+    f = t.getLocalData().getVectorData(0).copy()
+    dev = t.smoothFlux(f.copy(), 1)
+    monkeypatch.setenv("VR_HOST_SMOOTH", "1")
+    host = t.smoothFlux(f.copy(), 1)
+    assert dev.tobytes() == host.tobytes()
+    assert dev.tobytes() == o.smooth_flux(f.copy(), 1).tobytes()
+    assert not np.array_equal(dev, f)  # it did smooth something

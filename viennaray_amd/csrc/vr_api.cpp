@@ -1152,6 +1152,27 @@ int vr_smooth_flux(vr_context *c, float *flux, uint32_t n, int numNeighbors) {
     return fail(c, VR_E_INVALID, "vr_smooth_flux: bad argument");
   if (c->geo.geo != 0 || numNeighbors < 1)
     return VR_OK;
+  // device path: the geometry's own neighbourhood (numNeighbors == 1, what every reference
+  // example asks for) is resident with the device-built scene; no download of the CSR
+  if (numNeighbors == 1 && c->haveSetup && !c->geometryDirty && !std::getenv("VR_HOST_SMOOTH")) {
+    VR_HIP(c, hipSetDevice(c->device));
+    DevBuf<float> dIn, dOut;
+    DevBuf<uint32_t> dOv;
+    VR_HIP(c, dIn.ensure(n));
+    VR_HIP(c, dOut.ensure(n));
+    VR_HIP(c, dOv.ensure(1));
+    uint32_t ov = 0;
+    VR_HIP(c, hipMemcpyAsync(dIn.p, flux, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemsetAsync(dOv.p, 0, 4, c->stream));
+    VR_HIP(c, launch_smooth_flux(dIn.p, dOut.p, c->dNormal3.p, c->dNbOff.p, c->dNbIds.p, c->dOrder.p,
+                                 c->dLeafOfOrig.p, n, dOv.p, c->stream));
+    VR_HIP(c, hipMemcpyAsync(&ov, dOv.p, 4, hipMemcpyDeviceToHost, c->stream));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    if (ov == 0) {
+      VR_HIP(c, hipMemcpy(flux, dOut.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+      return VR_OK;
+    } // (some neighbourhood longer than the kernel's buffer: host path below)
+  }
   if (numNeighbors == 1) {
     int r = ensure_host_neighbors(c);
     if (r != VR_OK)

@@ -597,6 +597,59 @@ hipError_t launch_bvh_check(const SetupParams &s, unsigned *bad, hipStream_t st)
   return hipGetLastError();
 }
 
+// smoothFlux (rayTraceDisk.hpp:146-193) on the device neighbourhood: weighted average over the
+// neighbours whose normal points the same way, weights = normal dot products.  The sum runs
+// over the neighbours in ASCENDING ORIGINAL ID like the host path (float addition is ordered),
+// so both give the same bits: each thread sorts its (short) list first.  A list longer than the
+// local buffer raises *overflow and the host path takes over.
+constexpr unsigned SMOOTH_MAX = 48;
+__global__ void smooth_flux_kernel(const float *fluxIn, float *fluxOut, const float *normal3, const uint32_t *nbOff,
+                                   const uint32_t *nbIds, const uint32_t *order, const uint32_t *leafOfOrig,
+                                   unsigned n, unsigned *overflow) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const unsigned q = leafOfOrig[i];
+  const unsigned b = nbOff[q], e = nbOff[q + 1];
+  if (e - b > SMOOTH_MAX) {
+    atomicAdd(overflow, 1u);
+    fluxOut[i] = fluxIn[i];
+    return;
+  }
+  unsigned ids[SMOOTH_MAX];
+  unsigned cnt = 0;
+  for (unsigned j = b; j < e; ++j) { // insertion sort by original id
+    const unsigned o = order[nbIds[j]];
+    unsigned k = cnt++;
+    while (k > 0 && ids[k - 1] > o) {
+      ids[k] = ids[k - 1];
+      --k;
+    }
+    ids[k] = o;
+  }
+  const float nx = normal3[3 * (size_t)i], ny = normal3[3 * (size_t)i + 1], nz = normal3[3 * (size_t)i + 2];
+  float vv = fluxIn[i], sum = 1.f;
+  for (unsigned k = 0; k < cnt; ++k) {
+    const unsigned o = ids[k];
+    const float w = (nx * normal3[3 * (size_t)o] + ny * normal3[3 * (size_t)o + 1]) + nz * normal3[3 * (size_t)o + 2];
+    if (w > 0.f) {
+      vv += fluxIn[o] * w;
+      sum += w;
+    }
+  }
+  fluxOut[i] = vv / sum;
+}
+
+hipError_t launch_smooth_flux(const float *fluxIn, float *fluxOut, const float *normal3, const uint32_t *nbOff,
+                              const uint32_t *nbIds, const uint32_t *order, const uint32_t *leafOfOrig, unsigned n,
+                              unsigned *overflow, hipStream_t st) {
+  if (n == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(smooth_flux_kernel, dim3((n + 127) / 128), dim3(128), 0, st, fluxIn, fluxOut, normal3, nbOff, nbIds,
+                     order, leafOfOrig, n, overflow);
+  return hipGetLastError();
+}
+
 hipError_t launch_quantize_nodes(const float *nodes, unsigned numNodes, const float *base3, const float *scale3,
                                  uint32_t *qnodes, hipStream_t st) {
   if (numNodes == 0)
