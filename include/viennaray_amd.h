@@ -65,6 +65,7 @@ typedef struct vr_trace_info {
   int32_t error;
   uint64_t rngFullStates; /* diagnostic: rays that drew more than 156 numbers and continued
                              on the full 312-word engine state       */
+  double timeGenKernel;   /* seconds: the ray generator kernel(s) alone (HIP events)  */
 } vr_trace_info;
 
 /* gpu::Particle-style POD (rayParticle.hpp:208-218): a built-in particle.
@@ -113,6 +114,7 @@ int vr_set_rng_seed(vr_context *ctx, uint32_t seed);
 int vr_set_use_random_seeds(vr_context *ctx, int useRandom);
 /* KernelConfig::runNumber (rayUtil.hpp:93); apply() increments it           */
 int vr_set_run_number(vr_context *ctx, uint32_t runNumber);
+int vr_get_run_number(const vr_context *ctx, uint32_t *runNumber);
 
 /* Multi-GPU sharding hook (not in the reference): trace only the global ray
  * indices [first, first+count).  count == 0 restores "all rays".  Ray idx
@@ -135,6 +137,9 @@ uint32_t vr_num_primitives(const vr_context *ctx);
 int vr_get_flux(vr_context *ctx, float *out, uint32_t n);
 int vr_get_flux_f64(vr_context *ctx, double *out, uint32_t n);
 int vr_get_trace_info(const vr_context *ctx, vr_trace_info *out);
+/* which trace_kernel variant the last vr_apply_prepare selected: 0 general (reflection, roulette,
+ * RNG), 1 absorbing + flat scene, 2 absorbing + structured scene             */
+int vr_get_trace_mode(const vr_context *ctx, int32_t *mode);
 /* normalizeFlux / smoothFlux (rayTraceDisk.hpp:103-193, rayTraceTriangle.hpp:92-136),
  * in place on a caller buffer                                               */
 int vr_normalize_flux(vr_context *ctx, float *flux, uint32_t n, int normType);
@@ -180,6 +185,12 @@ int vr_debug_bvh_stats(vr_context *ctx, uint32_t *out3);
 /* consistency of the resident device-built BVH: number of internal nodes whose box is not
  * exactly the union of their children's or whose subtree size is inconsistent (expected 0)  */
 int vr_debug_bvh_check(vr_context *ctx, uint32_t *violations);
+
+/* Measurement aid (bench.py's roofline): the instruction-issue ceiling of the device for one of
+ * the instruction mixes the hot kernels are made of (0 f32 VALU independent, 1 f32 VALU dependent
+ * chain, 2 mt19937_64 seeding steps, 3 SALU, 4 packet-traversal VALU+SALU mix), at `wavesPerSimd`
+ * resident waves per SIMD.  out4 = {counted instructions / s, sustained clock Hz, seconds, count} */
+int vr_debug_issue_rate(vr_context *ctx, int kind, int wavesPerSimd, uint32_t iters, double *out4);
 
 #ifdef __cplusplus
 }

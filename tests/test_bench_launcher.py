@@ -1,0 +1,54 @@
+"""bench.py's own launcher path on CPU: `python bench.py --gpus N` with no RANK in the environment
+must start N ranks itself (torch.distributed.run child), shard the ray range, all-reduce and report
+n_gpus = N — rehearsed with the stand-in shard over gloo (the HIP tracer needs a GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout  # rank 0 prints ONE json line
+    return json.loads(lines[0])
+
+
+def _expected(total, n):
+    idx = (np.arange(total, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(n)
+    acc = np.bincount(idx.astype(np.int64), minlength=n).astype(np.int64)
+    return int(acc.sum()), int(acc.dot(np.arange(n, dtype=np.int64) % 1000003) % (1 << 61))
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 3])
+def test_gpus_flag_starts_that_many_ranks_weak(gpus):
+    out = _run(["--gpus", str(gpus), "--steps", "2", "--warmup", "0", "--stub-shard", "--grid", "50", "--rays", "10007"])
+    assert out["n_gpus"] == gpus and out["scaling"] == "weak"
+    assert out["total_rays"] == 10007 * gpus
+    s, c = _expected(10007 * gpus, 2500)
+    assert out["acc_sum"] == s and out["acc_checksum"] == c     # every ray traced exactly once
+    assert out["counters"]["totalRaysTraced"] == 10007 * gpus
+
+
+def test_total_rays_is_strong_scaling():
+    one = _run(["--gpus", "1", "--steps", "1", "--warmup", "0", "--stub-shard", "--grid", "50", "--total-rays", "30001"])
+    two = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--stub-shard", "--grid", "50", "--total-rays", "30001"])
+    assert one["scaling"] == two["scaling"] == "strong"
+    assert one["total_rays"] == two["total_rays"] == 30001
+    assert (one["acc_sum"], one["acc_checksum"]) == (two["acc_sum"], two["acc_checksum"]) == _expected(30001, 2500)
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--stub-shard"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)

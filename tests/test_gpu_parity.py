@@ -748,3 +748,64 @@ def test_device_smoothing_matches_host_and_oracle(geom, monkeypatch):
     assert dev.tobytes() == host.tobytes()
     assert dev.tobytes() == o.smooth_flux(f.copy(), 1).tobytes()
     assert not np.array_equal(dev, f)  # it did smooth something
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config C2 (the headline workload): P(1000) = 10^6 disks, PERIODIC, cosine source
+# ---------------------------------------------------------------------------
+def _c2_pair(sticking, total=100_000_000):
+    pts, nrm = vr.io.plane_grid(1000, 1.0)
+    t, o = make_pair_disks(pts, nrm, 1.0, 3, [BC.PERIODIC_BOUNDARY] * 3, TD.POS_Z, ("diffuse", sticking, 1.0),
+                           rays_fixed=total)
+    return t, o
+
+
+@pytest.mark.parametrize("sticking", [1.0, 0.1])
+def test_c2_million_disk_plane_matches_oracle(sticking):
+    """The first 10^7 rays of the 10^8-ray C2 stream (same global ray indices, same seed) against the
+    oracle: every counter equal, flux within the north-star tolerance (bit-equal for sticking 1)."""
+    t, o = _c2_pair(sticking)
+    t.setRayRange(0, 10_000_000)
+    o.set_ray_range(0, 10_000_000)
+    err, gi = compare(t, o, exact_flux=(sticking == 1.0))
+    assert gi["numRays"] == 100_000_000 and gi["geometryHits"] >= 10_000_000
+    assert t.traceMode() == (1 if sticking == 1.0 else 0)
+
+
+def test_c2_full_size_properties():
+    """C2 at its full 10^8 rays (no oracle at this size): conservation of trace segments, integer
+    flux for sticking 1, the analytic plane answer (SOURCE-normalised flux = 1), bit-identical
+    rerun, and two ray-range shards summing bit-exactly to the whole."""
+    pts, nrm = vr.io.plane_grid(1000, 1.0)
+    t = vr.TraceDisk(3)
+    t.setGeometry(pts, nrm, 1.0)
+    t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+    t.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+    t.setNumberOfRaysFixed(100_000_000)
+    t.setRngSeed(12345)
+    t.apply()
+    i = info_dict(t)
+    whole = t.getFluxF64()
+    assert i["numRays"] == 100_000_000
+    # a flat plane seen from above: every trace ends on the plane, on a wall (and goes on) or leaves
+    assert i["totalRaysTraced"] == i["geometryHits"] + i["nonGeometryHits"] + i["boundaryHits"]
+    assert i["geometryHits"] + i["nonGeometryHits"] == 100_000_000 and i["raysTerminated"] == 0
+    assert (whole == np.rint(whole)).all()                      # unit weights only
+    assert whole.sum() >= i["geometryHits"]                     # closest disk + overlapping neighbours
+    norm = t.normalizeFlux(whole.astype(np.float32))
+    assert abs(float(norm.mean()) - 1.0) < 2e-3                 # analytic: cosine source over a plane
+    assert abs(whole.sum() / i["geometryHits"] - np.pi * 0.75 * (1 + 1e-5) ** 2) < 2e-3  # pi r^2 / delta^2
+    # rerun with the same seed: bit-identical (tests/rngSeed/rngSeed.cpp:48-51 at full size)
+    t.setRunNumber(1)
+    t.apply()
+    assert (t.getFluxF64() == whole).all() and info_dict(t) == i
+    # two shards of the ray index range
+    parts = []
+    for first in (0, 50_000_000):
+        t.setRunNumber(1)
+        t.setRayRange(first, 50_000_000)
+        t.apply()
+        parts.append((t.getFluxF64(), info_dict(t)))
+    assert (parts[0][0] + parts[1][0] == whole).all()
+    for k in INFO_KEYS[1:]:
+        assert parts[0][1][k] + parts[1][1][k] == i[k], k

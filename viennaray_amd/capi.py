@@ -25,7 +25,8 @@ class TraceInfoPOD(C.Structure):
                 ("reflections", C.c_uint64), ("raysTerminated", C.c_uint64),
                 ("time", C.c_double), ("timeBuild", C.c_double), ("timeTrace", C.c_double),
                 ("timeTraceKernel", C.c_double),
-                ("warning", C.c_int32), ("error", C.c_int32), ("rngFullStates", C.c_uint64)]
+                ("warning", C.c_int32), ("error", C.c_int32), ("rngFullStates", C.c_uint64),
+                ("timeGenKernel", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -63,6 +64,7 @@ SIGNATURES = {
     "vr_set_rng_seed": (C.c_int, [_vp, C.c_uint32]),
     "vr_set_use_random_seeds": (C.c_int, [_vp, C.c_int]),
     "vr_set_run_number": (C.c_int, [_vp, C.c_uint32]),
+    "vr_get_run_number": (C.c_int, [_vp, _u32p]),
     "vr_set_ray_range": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
     "vr_apply": (C.c_int, [_vp]),
     "vr_apply_prepare": (C.c_int, [_vp]),
@@ -72,6 +74,7 @@ SIGNATURES = {
     "vr_get_flux": (C.c_int, [_vp, _fp, C.c_uint32]),
     "vr_get_flux_f64": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_uint32]),
     "vr_get_trace_info": (C.c_int, [_vp, C.POINTER(TraceInfoPOD)]),
+    "vr_get_trace_mode": (C.c_int, [_vp, _i32p]),
     "vr_normalize_flux": (C.c_int, [_vp, _fp, C.c_uint32, C.c_int]),
     "vr_smooth_flux": (C.c_int, [_vp, _fp, C.c_uint32, C.c_int]),
     "vr_get_disk_areas": (C.c_int, [_vp, _fp, C.c_uint32]),
@@ -86,6 +89,7 @@ SIGNATURES = {
     "vr_debug_intersect": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32, _i32p, _u32p, _fp]),
     "vr_debug_source_sample": (C.c_int, [_vp, _u64p, C.c_uint32, C.c_uint32, _fp, _fp]),
     "vr_debug_rng_outputs": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, _u64p]),
+    "vr_debug_issue_rate": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_double)]),
     "vr_debug_bvh_stats": (C.c_int, [_vp, _u32p]),
     "vr_debug_bvh_check": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
 }

@@ -115,6 +115,7 @@ struct vr_context {
   SetupParams lastSetup{};       // buffers of the resident device build (vr_debug_bvh_check)
   bool haveSetup = false;
   int builtOrderAxis = -1;       // child order of the resident BVH (source side first)
+  int bvhRefits = 0;             // 1 if the last build had to be re-fitted with agent-scope fences
   float builtOrderSign = 0.f;
   DevBuf<unsigned long long> dKeysA, dKeysB;
   bool hostOrderValid = false;   // c->bvh.order mirrors dOrder
@@ -132,6 +133,7 @@ struct vr_context {
   uint64_t rayFirstLaunch = 0, rayEndLaunch = 0;
   bool absorb = true;
   std::vector<hipEvent_t> evK; // trace-kernel event pairs, one per batch
+  std::vector<hipEvent_t> evG; // generator event pairs, one per batch
   double traceKernelSeconds = 0.0;
   size_t numBatches = 0;
   bool havePrimSticking = false;
@@ -218,6 +220,8 @@ void vr_destroy(vr_context *c) {
   c->dBinCount2.release();
   c->dScanTmp.release();
   for (auto e : c->evK)
+    (void)hipEventDestroy(e);
+  for (auto e : c->evG)
     (void)hipEventDestroy(e);
   if (c->ev0)
     (void)hipEventDestroy(c->ev0);
@@ -582,6 +586,10 @@ static int build_scene(vr_context *c) {
   s.nbOff = c->dNbOff.p;
   s.nbIds = nullptr;
   VR_HIP(c, launch_setup_bvh(s, c->dScanTmp.p, c->stream));
+  // every build is verified (one small kernel; its counter is read back with the syncs below):
+  // the fit's cross-workgroup hand-over is the one place the build relies on memory ordering
+  VR_HIP(c, hipMemsetAsync(c->dBounds.p + 6, 0, 4, c->stream));
+  VR_HIP(c, launch_bvh_check(s, c->dBounds.p + 6, c->stream));
   c->lastSetup = s;
   c->haveSetup = true;
   if (disk) {
@@ -600,10 +608,41 @@ static int build_scene(vr_context *c) {
     VR_HIP(c, c->dNbIds.ensure(1));
   }
   float root8[8];
-  uint32_t sz = 0;
+  uint32_t sz = 0, bad = 0;
   VR_HIP(c, hipMemcpyAsync(root8, c->dNodesPre.p, sizeof(root8), hipMemcpyDeviceToHost, c->stream));
   VR_HIP(c, hipMemcpyAsync(&sz, c->dSubSize.p, 4, hipMemcpyDeviceToHost, c->stream));
+  VR_HIP(c, hipMemcpyAsync(&bad, c->dBounds.p + 6, 4, hipMemcpyDeviceToHost, c->stream));
   VR_HIP(c, hipStreamSynchronize(c->stream));
+  c->bvhRefits = 0;
+  if (bad != 0) {
+    // never observed; the textbook agent-scope fences cost 3 ms per 10^6 primitives
+    s.strictFence = 1;
+    s.nbIds = nullptr;
+    VR_HIP(c, launch_fit_bvh(s, c->stream));
+    VR_HIP(c, hipMemsetAsync(c->dBounds.p + 6, 0, 4, c->stream));
+    VR_HIP(c, launch_bvh_check(s, c->dBounds.p + 6, c->stream));
+    VR_HIP(c, hipMemcpyAsync(root8, c->dNodesPre.p, sizeof(root8), hipMemcpyDeviceToHost, c->stream));
+    VR_HIP(c, hipMemcpyAsync(&sz, c->dSubSize.p, 4, hipMemcpyDeviceToHost, c->stream));
+    VR_HIP(c, hipMemcpyAsync(&bad, c->dBounds.p + 6, 4, hipMemcpyDeviceToHost, c->stream));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    c->bvhRefits = 1;
+    if (bad != 0)
+      return fail(c, VR_E_HIP, "device BVH build failed its consistency check twice");
+    if (disk) { // the neighbourhood was queried on the inconsistent tree: redo it
+      s.nbIds = nullptr;
+      VR_HIP(c, hipMemsetAsync(c->dNbOff.p + N, 0, 4, c->stream));
+      VR_HIP(c, launch_setup_neighbors(s, 0, c->stream));
+      VR_HIP(c, launch_scan(c->dNbOff.p, N + 1, c->dScanTmp.p, c->stream));
+      uint32_t total = 0;
+      VR_HIP(c, hipMemcpyAsync(&total, c->dNbOff.p + N, 4, hipMemcpyDeviceToHost, c->stream));
+      VR_HIP(c, hipStreamSynchronize(c->stream));
+      VR_HIP(c, c->dNbIds.ensure(total));
+      s.nbIds = c->dNbIds.p;
+      VR_HIP(c, launch_setup_neighbors(s, 1, c->stream));
+      VR_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->lastSetup = s;
+  }
   c->numNodes = sz & 0x7FFFFFFFu;
   c->bvh.numNodes = c->numNodes;
   c->bvh.numLeaves = 0;
@@ -788,10 +827,18 @@ int vr_apply_prepare(vr_context *c) {
       blocks = std::max(1, std::atoi(e));
     c->grid = (unsigned)c->numCUs * (unsigned)blocks;
   }
-  const size_t waves = (size_t)std::max(c->grid, (unsigned)c->numCUs * 8u) * (VR_BLOCK / 64);
-  if (waves > c->scratchWaves) {
-    VR_HIP(c, c->dScratch.ensure(waves * 312u * 64u));
-    c->scratchWaves = waves;
+  // tier-2 RNG slabs (312 x 64 words per resident wave): only a kernel that can draw more than
+  // 156 numbers per ray touches them — the general trace kernel and the tilted-source generator
+  {
+    size_t waves = 0;
+    if (!c->absorb)
+      waves = (size_t)c->grid * (VR_BLOCK / 64);
+    if (c->usePrimaryDirection)
+      waves = std::max(waves, (size_t)c->numCUs * 8u * (VR_BLOCK / 64)); // launch_gen's grid bound
+    if (waves > c->scratchWaves) {
+      VR_HIP(c, c->dScratch.ensure(waves * 312u * 64u));
+      c->scratchWaves = waves;
+    }
   }
 
   p.nodes = c->dNodes.p;
@@ -937,7 +984,14 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   if (c->overlap && batchNo >= 2)
     VR_HIP(c, hipStreamWaitEvent(sg, c->evTraced[batchNo - 2], 0));
   VR_HIP(c, hipMemsetAsync(p.binCount, 0, ((size_t)p.numBins + 1) * 4, sg));
+  while (c->evG.size() < 2 * (batchNo + 1)) {
+    hipEvent_t e;
+    VR_HIP(c, hipEventCreate(&e));
+    c->evG.push_back(e);
+  }
+  VR_HIP(c, hipEventRecord(c->evG[2 * batchNo], sg));
   VR_HIP(c, launch_gen(p, c->geo.D, keepRng, (unsigned)c->numCUs * 8u, sg));
+  VR_HIP(c, hipEventRecord(c->evG[2 * batchNo + 1], sg));
   // tracer
   if (c->overlap) {
     VR_HIP(c, hipEventRecord(c->evSort[batchNo], sg));
@@ -1024,6 +1078,13 @@ int vr_apply_finish(vr_context *c) {
     kms += m;
   }
   i.timeTraceKernel = kms * 1e-3;
+  double gms = 0.0;
+  for (size_t b = 0; b < c->numBatches; ++b) {
+    float m = 0.f;
+    VR_HIP(c, hipEventElapsedTime(&m, c->evG[2 * b], c->evG[2 * b + 1]));
+    gms += m;
+  }
+  i.timeGenKernel = gms * 1e-3;
   i.timeBuild = c->buildSeconds;
   i.time = i.timeBuild + i.timeTrace;
   ++c->runNumber; // rayTraceDisk.hpp:54
@@ -1078,6 +1139,13 @@ int vr_get_trace_info(const vr_context *c, vr_trace_info *out) {
   if (!c || !out)
     return VR_E_INVALID;
   *out = c->info;
+  return VR_OK;
+}
+
+int vr_get_trace_mode(const vr_context *c, int32_t *mode) {
+  if (!c || !mode)
+    return VR_E_INVALID;
+  *mode = c->traceMode;
   return VR_OK;
 }
 
@@ -1342,6 +1410,49 @@ int vr_debug_bvh_check(vr_context *c, uint32_t *violations) {
   VR_HIP(c, launch_bvh_check(c->lastSetup, dBad.p, c->stream));
   VR_HIP(c, hipMemcpyAsync(violations, dBad.p, 4, hipMemcpyDeviceToHost, c->stream));
   VR_HIP(c, hipStreamSynchronize(c->stream));
+  return VR_OK;
+}
+
+int vr_get_run_number(const vr_context *c, uint32_t *out) {
+  if (!c || !out)
+    return VR_E_INVALID;
+  *out = c->runNumber;
+  return VR_OK;
+}
+
+// Measured instruction-issue ceiling (vr_bench.hip): `wavesPerSimd` blocks of 256 threads per CU
+// (= that many waves on every SIMD) run `iters` passes of the chosen mix.
+// out4 = {counted instructions per second, sustained clock in Hz (median over waves),
+//         seconds (HIP events), counted instructions}
+int vr_debug_issue_rate(vr_context *c, int kind, int wavesPerSimd, uint32_t iters, double *out4) {
+  if (!c || !out4 || kind < 0 || kind > 4 || wavesPerSimd < 1 || wavesPerSimd > 8 || iters == 0)
+    return fail(c, VR_E_INVALID, "vr_debug_issue_rate: bad argument");
+  VR_HIP(c, hipSetDevice(c->device));
+  const unsigned blocks = (unsigned)c->numCUs * (unsigned)wavesPerSimd;
+  const size_t waves = (size_t)blocks * 4;
+  DevBuf<unsigned long long> dOut;
+  VR_HIP(c, dOut.ensure(waves * 3));
+  VR_HIP(c, hipMemsetAsync(dOut.p, 0, waves * 24, c->stream));
+  VR_HIP(c, launch_issue_kernel(kind, blocks, std::max<uint32_t>(iters / 16, 1), dOut.p, c->stream)); // warm-up, clocks up
+  VR_HIP(c, hipEventRecord(c->ev0, c->stream));
+  VR_HIP(c, launch_issue_kernel(kind, blocks, iters, dOut.p, c->stream));
+  VR_HIP(c, hipEventRecord(c->ev1, c->stream));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
+  float ms = 0.f;
+  VR_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  std::vector<unsigned long long> h(waves * 3);
+  VR_HIP(c, hipMemcpy(h.data(), dOut.p, waves * 24, hipMemcpyDeviceToHost));
+  std::vector<double> clk;
+  for (size_t w = 0; w < waves; ++w)
+    if (h[3 * w + 1])
+      clk.push_back((double)h[3 * w] / (double)h[3 * w + 1] * 1e8);
+  std::sort(clk.begin(), clk.end());
+  const double perPass = kind == 4 ? 24.0 : 32.0;
+  const double counted = (double)waves * (double)iters * perPass;
+  out4[0] = counted / (ms * 1e-3);
+  out4[1] = clk.empty() ? 0.0 : clk[clk.size() / 2];
+  out4[2] = ms * 1e-3;
+  out4[3] = counted;
   return VR_OK;
 }
 

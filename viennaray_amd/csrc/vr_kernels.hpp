@@ -19,6 +19,7 @@ hipError_t launch_debug_rng(unsigned seed32, unsigned count, unsigned long long 
                             hipStream_t s);
 // device-side setup (vr_setup.hip)
 hipError_t launch_setup_bvh(const SetupParams &s, unsigned *scanTmp, hipStream_t st);
+hipError_t launch_fit_bvh(const SetupParams &s, hipStream_t st);
 hipError_t launch_bvh_check(const SetupParams &s, unsigned *bad, hipStream_t st);
 hipError_t launch_smooth_flux(const float *fluxIn, float *fluxOut, const float *normal3, const uint32_t *nbOff,
                               const uint32_t *nbIds, const uint32_t *order, const uint32_t *leafOfOrig, unsigned n,
@@ -28,5 +29,8 @@ hipError_t launch_quantize_nodes(const float *nodes, unsigned numNodes, const fl
 hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st);
 hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, unsigned replicas,
                               const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, hipStream_t s);
+
+// issue-ceiling microbenchmarks (vr_bench.hip); out: one {cycles, realtime, sink} triple of u64 per wave
+hipError_t launch_issue_kernel(int kind, unsigned blocks, unsigned iters, void *out, hipStream_t s);
 
 } // namespace vr

@@ -278,14 +278,24 @@ __global__ void fit_kernel(SetupParams s) {
   unsigned p = s.parentLeaf[q] & 0x7FFFFFFFu;
   for (;;) {
     // Hand-over between the two arrivers of a node.  Everything a fitter publishes (box, subtree
-    // size) is written with agent-scope atomic stores and read with agent-scope atomic loads,
-    // which are coherent across the XCDs by themselves; what remains is ORDER: the stores must
-    // have completed before the arrival counter is bumped.  A workgroup-scope release fence is
-    // exactly that wait (s_waitcnt vmcnt(0)) without the L2 write-back an agent-scope fence
-    // adds for plain stores — which this kernel does not rely on (3.0 -> 0.3 ms on 10^6 disks).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (__hip_atomic_fetch_add(&s.arrive[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+    // size) is written with agent-scope atomic stores (`global_store ... sc1`: write-through, not
+    // kept in this XCD's L2) and read with agent-scope atomic loads (`sc1`: served below the
+    // reader's L1), which are coherent across the XCDs by themselves; what remains is ORDER: every
+    // such store of this lane must have been acknowledged before the arrival counter is bumped.
+    // That is the explicit `s_waitcnt vmcnt(0)` below (inline asm: no compiler pass can drop or
+    // move it; tests/test_isa_contracts.py checks the emitted ISA).  It replaces an agent-scope
+    // release fence, whose `buffer_wbl2` write-back of the whole L2 made this kernel 3.0 ms instead
+    // of 0.2 ms on 10^6 disks and which these sc1 stores do not need.  s.strictFence selects the
+    // textbook form (agent-scope release / acquire fences) instead: build_scene() re-runs the fit
+    // that way should launch_bvh_check ever report a violation.
+    if (s.strictFence)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned arrived = __hip_atomic_fetch_add(&s.arrive[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrived == 0u)
       return; // first arriver: the sibling will come
+    if (s.strictFence)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const unsigned L = s.childL[p], R = s.childR[p];
     const float *a = (L & CHILD_LEAF) ? s.sbox + 6 * (size_t)(L & ~CHILD_LEAF) : s.nodeBox + 6 * (size_t)L;
     const float *b = (R & CHILD_LEAF) ? s.sbox + 6 * (size_t)(R & ~CHILD_LEAF) : s.nodeBox + 6 * (size_t)R;
@@ -557,12 +567,22 @@ hipError_t launch_setup_bvh(const SetupParams &sp, unsigned *scanTmp, hipStream_
   }
   // (8 passes: result is back in A)
   hipLaunchKernelGGL(pack_kernel, dim3(g256), dim3(256), 0, st, s);
+  if (n > 1)
+    hipLaunchKernelGGL(karras_kernel, dim3((n - 1 + 255) / 256), dim3(256), 0, st, s);
+  return launch_fit_bvh(s, st);
+}
+
+// bottom-up fit + traversal-node emission over the resident radix tree (also the re-run with
+// s.strictFence after a failed launch_bvh_check)
+hipError_t launch_fit_bvh(const SetupParams &s, hipStream_t st) {
+  const unsigned n = s.n;
+  if (n == 0)
+    return hipSuccess;
   if (n > 1) {
-    e = hipMemsetAsync(s.arrive, 0, (size_t)(n - 1) * 4, st);
+    hipError_t e = hipMemsetAsync(s.arrive, 0, (size_t)(n - 1) * 4, st);
     if (e != hipSuccess)
       return e;
-    hipLaunchKernelGGL(karras_kernel, dim3((n - 1 + 255) / 256), dim3(256), 0, st, s);
-    hipLaunchKernelGGL(fit_kernel, dim3(g256), dim3(256), 0, st, s);
+    hipLaunchKernelGGL(fit_kernel, dim3((n + 255) / 256), dim3(256), 0, st, s);
   }
   hipLaunchKernelGGL(finalize_kernel, dim3((2 * n - 1 + 255) / 256), dim3(256), 0, st, s);
   return hipGetLastError();

@@ -101,6 +101,7 @@ struct SetupParams {
   uint32_t leafMax;       // subtrees of <= leafMax primitives become one leaf (<= 15)
   int32_t orderAxis;      // children are ordered along this axis ...
   float orderSign;        // ... larger sign * coordinate (= nearer the source plane) first
+  int32_t strictFence;    // fit_kernel: agent-scope release/acquire fences around the arrival counter (fallback)
   // work buffers
   float *box, *sbox;      // 6 per primitive: original order / sorted order
   uint32_t *bounds;       // 6 ordered-uint scene bounds

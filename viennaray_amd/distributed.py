@@ -32,24 +32,37 @@ class GpuShard:
     so the all-reduce runs on the buffer the gather kernel wrote."""
 
     def __init__(self, tracer, device):
-        import torch
         self.tr = tracer
         self.device = device
-        self.acc = torch.zeros(tracer._n, dtype=torch.int64, device=device)
-        tracer.bindFluxAccumulators(self.acc.data_ptr(), tracer._n)
+        self.acc = None
+        self.last_info = None
+        self._bind()
+
+    def _bind(self):
+        """(Re-)bind the accumulator tensor.  setGeometry() drops an external binding (the
+        primitive count may have changed), so this runs before every launch."""
+        import torch
+        n = self.tr._n
+        if self.acc is None or self.acc.numel() != n:
+            self.acc = torch.zeros(n, dtype=torch.int64, device=self.device)
+        self.tr.bindFluxAccumulators(self.acc.data_ptr(), n)
 
     def trace_local(self, first, count, run_number=None):
         import torch
         if run_number is not None:
             self.tr.setRunNumber(run_number)
-        self.tr.setRayRange(first, count)
-        self.tr.applyPrepare()
+        self._bind()
         if count > 0:
+            self.tr.setRayRange(first, count)
+            self.tr.applyPrepare()
             self.tr.applyLaunch()
-            self.tr.applyFinish(collect=False)
+            self.tr.applyFinish(collect=False)   # ++runNumber, like every apply()
             info = self.tr.getRayTraceInfo()
             cnt = [int(getattr(info, k)) for k in COUNTER_KEYS]
         else:
+            # an empty shard still counts as one apply(): every rank must enter the next
+            # apply() with the same runNumber, i.e. the same seed (rayTraceDisk.hpp:54)
+            self.tr.skipApply()
             self.acc.zero_()
             info = None
             cnt = [0] * len(COUNTER_KEYS)

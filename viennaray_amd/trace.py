@@ -240,6 +240,16 @@ class Trace:
     def setRunNumber(self, r):
         self._check(self._L.vr_set_run_number(self._h, int(r)))
 
+    def getRunNumber(self):
+        v = C.c_uint32(0)
+        self._check(self._L.vr_get_run_number(self._h, C.byref(v)))
+        return int(v.value)
+
+    def skipApply(self):
+        """What an apply() does to the run number (rayTraceDisk.hpp:54) without tracing: a rank
+        whose ray shard is empty stays in step with the others' seeds."""
+        self.setRunNumber(self.getRunNumber() + 1)
+
     def setRayRange(self, first, count):
         self._check(self._L.vr_set_ray_range(self._h, int(first), int(count)))
 
@@ -281,6 +291,12 @@ class Trace:
         pod = TraceInfoPOD()
         self._check(self._L.vr_get_trace_info(self._h, C.byref(pod)))
         return pod
+
+    def traceMode(self):
+        """trace_kernel variant of the last prepare: 0 general, 1 absorbing/flat, 2 absorbing/structured"""
+        v = C.c_int32(0)
+        self._check(self._L.vr_get_trace_mode(self._h, C.byref(v)))
+        return int(v.value)
 
     def normalizeFlux(self, flux, norm=NormalizationType.SOURCE):
         f = np.ascontiguousarray(flux, dtype=np.float32).copy()
@@ -339,6 +355,12 @@ class Trace:
         self._check(self._L.vr_debug_rng_outputs(self._h, int(idx), int(seed), count,
                                                  out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out
+
+    def debugIssueRate(self, kind, waves_per_simd, iters=20000):
+        """Measured issue ceiling: dict(rate [counted instr/s], clock_hz, seconds, count)."""
+        out = (C.c_double * 4)()
+        self._check(self._L.vr_debug_issue_rate(self._h, int(kind), int(waves_per_simd), int(iters), out))
+        return dict(rate=out[0], clock_hz=out[1], seconds=out[2], count=out[3])
 
     def debugBvhCheck(self):
         v = C.c_uint32(0)
