@@ -140,9 +140,13 @@ int vr_get_trace_info(const vr_context *ctx, vr_trace_info *out);
 /* which trace_kernel variant the last vr_apply_prepare selected: 0 general (reflection, roulette,
  * RNG), 1 absorbing + flat scene, 2 absorbing + structured scene             */
 int vr_get_trace_mode(const vr_context *ctx, int32_t *mode);
-/* normalizeFlux / smoothFlux (rayTraceDisk.hpp:103-193, rayTraceTriangle.hpp:92-136),
- * in place on a caller buffer                                               */
+/* normalizeFlux / smoothFlux (rayTraceDisk.hpp:103-193, rayTraceTriangle.hpp:92-136), in place on
+ * a caller buffer; both run as HIP kernels on the resident areas / neighbourhood (upload, kernel,
+ * download)                                                                                   */
 int vr_normalize_flux(vr_context *ctx, float *flux, uint32_t n, int normType);
+/* getLocalData().getVectorData(0) + normalizeFlux fused on the device: the raw flux never visits
+ * the host (accumulators -> float -> flux * sourceArea / (numRays * area), one download)     */
+int vr_get_flux_normalized(vr_context *ctx, float *out, uint32_t n, int normType);
 int vr_smooth_flux(vr_context *ctx, float *flux, uint32_t n, int numNeighbors);
 /* geometry-derived values the reference exposes to its tests                */
 int vr_get_disk_areas(vr_context *ctx, float *out, uint32_t n);
@@ -188,7 +192,8 @@ int vr_debug_bvh_check(vr_context *ctx, uint32_t *violations);
 
 /* Measurement aid (bench.py's roofline): the instruction-issue ceiling of the device for one of
  * the instruction mixes the hot kernels are made of (0 f32 VALU independent, 1 f32 VALU dependent
- * chain, 2 mt19937_64 seeding steps, 3 SALU, 4 packet-traversal VALU+SALU mix), at `wavesPerSimd`
+ * chain, 2 mt19937_64 seeding steps, 3 SALU, 4 packet-traversal VALU+SALU mix,
+ * 5 independent VALU+SALU mix), at `wavesPerSimd`
  * resident waves per SIMD.  out4 = {counted instructions / s, sustained clock Hz, seconds, count} */
 int vr_debug_issue_rate(vr_context *ctx, int kind, int wavesPerSimd, uint32_t iters, double *out4);
 

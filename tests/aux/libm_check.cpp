@@ -44,5 +44,26 @@ int main(int argc, char **argv) {
     std::printf("powf(x, %.9g): %ld inputs, mismatches %ld\n", ee, m, bad);
     badP += bad;
   }
-  return (badS || badC || badP) ? 1 : 0;
+  // acosf on every float in [-1, 1] and sinf on [0, 2*pi] (disk-area intersector)
+  long badA = 0, nA = 0, badSf = 0;
+  {
+    const uint32_t one = vr::vr_asuint(1.0f);
+#pragma omp parallel for reduction(+ : badA, nA) schedule(static)
+    for (long u = 0; u <= (long)one; u += step) {
+      for (int sg = 0; sg < 2; ++sg) {
+        const float x = vr::vr_asfloat((uint32_t)u | (sg ? 0x80000000u : 0u));
+        const float a = acosf(x), b = vr::glibc_acosf(x);
+        badA += std::memcmp(&a, &b, 4) != 0;
+        ++nA;
+      }
+    }
+#pragma omp parallel for reduction(+ : badSf) schedule(static)
+    for (long u = 0; u <= (long)hi; u += step) {
+      const float x = vr::vr_asfloat((uint32_t)u);
+      const float a = sinf(x), b = vr::glibc_sinf(x);
+      badSf += std::memcmp(&a, &b, 4) != 0;
+    }
+  }
+  std::printf("acosf: %ld inputs, mismatches %ld; sinf mismatches %ld\n", nA, badA, badSf);
+  return (badS || badC || badP || badA || badSf) ? 1 : 0;
 }

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 import viennaray_amd as vr  # noqa: E402
 
 KINDS = {0: "valu_f32_independent", 1: "valu_f32_dependent_chain", 2: "mt19937_64_seed_step",
-         3: "salu", 4: "packet_mix_24valu_16salu"}
+         3: "salu", 4: "packet_mix_24valu_16salu", 5: "independent_mix_24valu_16salu"}
 
 
 def main():
@@ -37,7 +37,7 @@ def main():
             else:
                 row["per_simd_cycle"] = r["rate"] / (simds * clk)
                 row["cycles_per_wave_instr"] = simds * clk / r["rate"]
-            if kind == 4:
+            if kind >= 4:
                 row["salu_per_cu_cycle"] = r["rate"] * (16.0 / 24.0) / (cus * clk)
             rows.append(row)
             print(json.dumps(row))

@@ -76,6 +76,7 @@ SIGNATURES = {
     "vr_get_trace_info": (C.c_int, [_vp, C.POINTER(TraceInfoPOD)]),
     "vr_get_trace_mode": (C.c_int, [_vp, _i32p]),
     "vr_normalize_flux": (C.c_int, [_vp, _fp, C.c_uint32, C.c_int]),
+    "vr_get_flux_normalized": (C.c_int, [_vp, _fp, C.c_uint32, C.c_int]),
     "vr_smooth_flux": (C.c_int, [_vp, _fp, C.c_uint32, C.c_int]),
     "vr_get_disk_areas": (C.c_int, [_vp, _fp, C.c_uint32]),
     "vr_get_bounding_box": (C.c_int, [_vp, _fp]),

@@ -61,7 +61,8 @@ struct vr_context {
   bool configDirty = true;   // bbox / walls / areas / sticking map need recomputing
   Bvh bvh;
   std::vector<uint32_t> leafOfOrig;
-  std::vector<float> diskAreas;
+  std::vector<float> diskAreas;       // host mirror of dAreas (disks), downloaded on demand
+  bool diskAreasHostValid = false;
 
   // Trace<T,D> configuration (rayTrace.hpp:157-179, rayUtil.hpp:83-94)
   int bcs[3] = {0, 0, 0};
@@ -95,6 +96,8 @@ struct vr_context {
 
   // device buffers
   DevBuf<float> dNodes, dPrims, dPrimSticking;
+  DevBuf<float> dAreas, dFluxTmp;     // exposed area per primitive (caller's order); normalisation scratch
+  bool areasValid = false;
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
   DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
   size_t scratchWaves = 0;
@@ -243,6 +246,7 @@ int vr_set_disks(vr_context *c, const float *points, const float *normals, uint3
     return fail(c, VR_E_INVALID, "vr_set_disks: bad argument");
   host_set_disks(c->geo, points, normals, n, gridDelta, diskRadius, D);
   c->hostNeighborsValid = false;
+  c->areasValid = false;
   c->boundFlux = nullptr;
   c->geometryDirty = true;
   c->configDirty = true;
@@ -258,6 +262,7 @@ int vr_set_triangles(vr_context *c, const float *verts, uint32_t nverts, const u
     if (tris[i] >= nverts)
       return fail(c, VR_E_INVALID, "vr_set_triangles: vertex index out of range");
   host_set_triangles(c->geo, verts, nverts, tris, ntris, gridDelta, D);
+  c->areasValid = false;
   c->boundFlux = nullptr;
   c->geometryDirty = true;
   c->configDirty = true;
@@ -710,8 +715,6 @@ int vr_apply_prepare(vr_context *c) {
     // rayBoundary.hpp:23-25: conditions are picked by AXIS
     c->boundaryConds[0] = c->bcs[c->ts[1]];
     c->boundaryConds[1] = (D == 2 && c->ts[2] >= 2) ? 0 : c->bcs[c->ts[2]];
-    if (c->geo.geo == 0)
-      host_disk_areas(c->geo, c->boundaryConds, c->ts[1], c->ts[2], c->diskAreas);
     // SourceRandom::getSourceArea (raySourceRandom.hpp:40-47)
     const int f = c->ts[1], s = c->ts[2];
     c->sourceArea = D == 2 ? (c->bbHi[f] - c->bbLo[f]) : (c->bbHi[f] - c->bbLo[f]) * (c->bbHi[s] - c->bbLo[s]);
@@ -730,6 +733,39 @@ int vr_apply_prepare(vr_context *c) {
     c->geometryDirty = false;
     c->builtOrderAxis = c->ts[0];
     c->builtOrderSign = c->ts[3] ? 1.f : -1.f;
+  }
+  // exposed area of every primitive, resident on the device for normalizeFlux
+  // (computeDiskAreas, rayGeometryDisk.hpp:266-354: one thread per disk; triangle areas come
+  // with the mesh, rayGeometryTriangle.hpp:145-176)
+  if (redoConfig || !c->areasValid) {
+    VR_HIP(c, c->dAreas.ensure(N));
+    c->diskAreasHostValid = false;
+    if (c->geo.geo == 0) {
+      AreaParams ap{};
+      ap.D = D;
+      ap.firstDir = c->ts[1];
+      ap.secondDir = c->ts[2];
+      // rayGeometryDisk.hpp:281-284 indexes the 2-entry BC array by AXIS; axis 2 is out of
+      // range there, entry 1 is used for it
+      ap.bcFirst = c->boundaryConds[c->ts[1] > 1 ? 1 : c->ts[1]];
+      ap.bcSecond = c->boundaryConds[c->ts[2] > 1 ? 1 : c->ts[2]];
+      for (int k = 0; k < 3; ++k) {
+        ap.minC[k] = c->geo.minC[k];
+        ap.maxC[k] = c->geo.maxC[k];
+      }
+      const char *hb = std::getenv("VR_HOST_BUILD");
+      if (hb && std::atoi(hb)) {
+        host_disk_areas(c->geo, ap, c->diskAreas);
+        VR_HIP(c, hipMemcpy(c->dAreas.p, c->diskAreas.data(), (size_t)N * 4, hipMemcpyHostToDevice));
+        c->diskAreasHostValid = true;
+      } else {
+        VR_HIP(c, launch_disk_areas(c->dDisk4.p, c->dNormal3.p, N, ap, c->dAreas.p, c->stream));
+      }
+    } else {
+      VR_HIP(c, hipMemcpyAsync(c->dAreas.p, c->geo.triAreas.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+      VR_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    c->areasValid = true;
   }
   // per-primitive sticking from the material map (gpu::Particle-style, rayParticle.hpp:208-218)
   if (redoConfig)
@@ -1187,30 +1223,57 @@ int vr_bind_flux_accumulators(vr_context *c, void *devPtr, uint32_t n) {
 
 void *vr_stream(vr_context *c) { return c ? (void *)c->stream : nullptr; }
 
-// rayTraceDisk.hpp:103-142, rayTraceTriangle.hpp:92-130
+// normalizeFlux on the device (rayTraceDisk.hpp:103-142, rayTraceTriangle.hpp:92-130;
+// gpu/kernels/normKernels.cu:58-74): dFluxTmp holds the flux in the caller's order
+static int normalize_on_device(vr_context *c, uint32_t n, int normType) {
+  const bool disk = c->geo.geo == 0;
+  if (!c->areasValid)
+    return fail(c, VR_E_STATE, "vr_normalize_flux: call vr_apply first (primitive areas)");
+  float normFactor = 0.f;
+  if (normType == VR_NORM_SOURCE) {
+    if (c->numRaysLast == 0)
+      return fail(c, VR_E_STATE, "No source was specified in rayTrace for the normalization.");
+    normFactor = c->sourceArea / c->numRaysLast;
+  } else if (normType != VR_NORM_MAX) {
+    return VR_OK; // `default: break;` in the reference
+  }
+  const double totalDiskArea = c->geo.diskRadius * c->geo.diskRadius * M_PI;
+  VR_HIP(c, launch_normalize_flux(c->dFluxTmp.p, c->dAreas.p, n, disk ? 0 : 1, normType, normFactor, totalDiskArea,
+                                  c->dBounds.p + 7, c->stream));
+  return VR_OK;
+}
+
 int vr_normalize_flux(vr_context *c, float *flux, uint32_t n, int normType) {
   if (!c || !flux || n != c->geo.numPrims)
     return fail(c, VR_E_INVALID, "vr_normalize_flux: bad argument");
-  const bool disk = c->geo.geo == 0;
-  if (disk && c->diskAreas.size() != n)
-    return fail(c, VR_E_STATE, "vr_normalize_flux: call vr_apply first (disk areas)");
-  if (normType == VR_NORM_MAX) {
-    const float maxv = *std::max_element(flux, flux + n);
-    if (disk) {
-      const auto total = c->geo.diskRadius * c->geo.diskRadius * M_PI;
-      for (uint32_t i = 0; i < n; ++i)
-        flux[i] *= (total / c->diskAreas[i]) / maxv;
-    } else {
-      for (uint32_t i = 0; i < n; ++i)
-        flux[i] /= maxv * c->geo.triAreas[i];
-    }
-  } else {
-    if (c->numRaysLast == 0)
-      return fail(c, VR_E_STATE, "No source was specified in rayTrace for the normalization.");
-    const float normFactor = c->sourceArea / c->numRaysLast;
-    for (uint32_t i = 0; i < n; ++i)
-      flux[i] *= normFactor / (disk ? c->diskAreas[i] : c->geo.triAreas[i]);
-  }
+  VR_HIP(c, hipSetDevice(c->device));
+  VR_HIP(c, c->dFluxTmp.ensure(n));
+  VR_HIP(c, hipMemcpyAsync(c->dFluxTmp.p, flux, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+  int r = normalize_on_device(c, n, normType);
+  if (r != VR_OK)
+    return r;
+  VR_HIP(c, hipMemcpyAsync(flux, c->dFluxTmp.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
+  return VR_OK;
+}
+
+// getLocalData().getVectorData(0) followed by normalizeFlux, without the raw flux ever
+// visiting the host: int64 accumulators -> float -> normalised, one download
+int vr_get_flux_normalized(vr_context *c, float *out, uint32_t n, int normType) {
+  if (!c || !out)
+    return VR_E_INVALID;
+  if (!c->haveResult)
+    return fail(c, VR_E_STATE, "vr_get_flux_normalized: no result (call vr_apply)");
+  if (n != c->geo.numPrims)
+    return fail(c, VR_E_INVALID, "vr_get_flux_normalized: size mismatch");
+  VR_HIP(c, hipSetDevice(c->device));
+  VR_HIP(c, c->dFluxTmp.ensure(n));
+  VR_HIP(c, launch_flux_from_acc(c->fluxOut(), n, c->dFluxTmp.p, c->stream));
+  int r = normalize_on_device(c, n, normType);
+  if (r != VR_OK)
+    return r;
+  VR_HIP(c, hipMemcpyAsync(out, c->dFluxTmp.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
   return VR_OK;
 }
 
@@ -1276,8 +1339,15 @@ int vr_smooth_flux(vr_context *c, float *flux, uint32_t n, int numNeighbors) {
 }
 
 int vr_get_disk_areas(vr_context *c, float *out, uint32_t n) {
-  if (!c || !out || n != c->geo.numPrims || c->diskAreas.size() != n)
+  if (!c || !out || n != c->geo.numPrims || c->geo.geo != 0 || !c->areasValid)
     return fail(c, VR_E_STATE, "vr_get_disk_areas: not available");
+  if (!c->diskAreasHostValid) {
+    VR_HIP(c, hipSetDevice(c->device));
+    c->diskAreas.resize(n);
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    VR_HIP(c, hipMemcpy(c->diskAreas.data(), c->dAreas.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    c->diskAreasHostValid = true;
+  }
   std::memcpy(out, c->diskAreas.data(), (size_t)n * 4);
   return VR_OK;
 }
@@ -1425,7 +1495,7 @@ int vr_get_run_number(const vr_context *c, uint32_t *out) {
 // out4 = {counted instructions per second, sustained clock in Hz (median over waves),
 //         seconds (HIP events), counted instructions}
 int vr_debug_issue_rate(vr_context *c, int kind, int wavesPerSimd, uint32_t iters, double *out4) {
-  if (!c || !out4 || kind < 0 || kind > 4 || wavesPerSimd < 1 || wavesPerSimd > 8 || iters == 0)
+  if (!c || !out4 || kind < 0 || kind > 5 || wavesPerSimd < 1 || wavesPerSimd > 8 || iters == 0)
     return fail(c, VR_E_INVALID, "vr_debug_issue_rate: bad argument");
   VR_HIP(c, hipSetDevice(c->device));
   const unsigned blocks = (unsigned)c->numCUs * (unsigned)wavesPerSimd;
@@ -1447,7 +1517,7 @@ int vr_debug_issue_rate(vr_context *c, int kind, int wavesPerSimd, uint32_t iter
     if (h[3 * w + 1])
       clk.push_back((double)h[3 * w] / (double)h[3 * w + 1] * 1e8);
   std::sort(clk.begin(), clk.end());
-  const double perPass = kind == 4 ? 24.0 : 32.0;
+  const double perPass = kind >= 4 ? 24.0 : 32.0;
   const double counted = (double)waves * (double)iters * perPass;
   out4[0] = counted / (ms * 1e-3);
   out4[1] = clk.empty() ? 0.0 : clk[clk.size() / 2];

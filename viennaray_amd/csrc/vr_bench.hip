@@ -11,7 +11,8 @@
 //   KIND 2  64-bit integer multiply-add chain = mt_step of the generator (mt19937_64 seeding)
 //   KIND 3  SALU : s_add_u32 / s_and_b32 / s_lshl_b32 / s_xor_b32 on independent registers
 //   KIND 4  packet-traversal mix: 24 VALU + 16 SALU interleaved, SALU consuming a VALU compare
-//           (v_cmp -> s_and_b64 -> s_bcnt1), i.e. the vote pattern of bvh_hit_packet
+//           (v_cmp -> s_and_b64), i.e. the vote pattern of bvh_hit_packet
+//   KIND 5  24 VALU + 16 SALU interleaved, the two streams independent (can they co-issue?)
 //
 // Every wave runs `iters` passes over an unrolled body with a known instruction count, so
 // rate = waves x iters x body / time (HIP events); rocprofv3's SQ_INSTS_VALU / SQ_INSTS_SALU
@@ -69,6 +70,13 @@ template <int KIND> __global__ __launch_bounds__(256) void issue_kernel(unsigned
                    : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)
                    :
                    : "scc");
+    } else if (KIND == 5) {
+      // 24 VALU + 16 SALU per pass, the two streams independent of each other
+      asm volatile(VR_REP8("v_fma_f32 %0, %0, %6, %7\n v_min_f32 %1, %1, %7\n s_add_u32 %4, %4, 1\n"
+                           "v_fma_f32 %2, %2, %6, %7\n s_xor_b32 %5, %5, %4\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1)
+                   : "v"(m), "v"(c)
+                   : "scc");
     } else {
       // 24 VALU + 16 SALU per pass: slab-test arithmetic, a vote, scalar bookkeeping
       asm volatile(VR_REP8("v_fma_f32 %0, %0, %4, %5\n v_min_f32 %1, %1, %0\n s_add_u32 %2, %2, 1\n"
@@ -100,6 +108,7 @@ hipError_t launch_issue_kernel(int kind, unsigned blocks, unsigned iters, void *
   case 1: hipLaunchKernelGGL((issue_kernel<1>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
   case 2: hipLaunchKernelGGL((issue_kernel<2>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
   case 3: hipLaunchKernelGGL((issue_kernel<3>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
+  case 5: hipLaunchKernelGGL((issue_kernel<5>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
   default: hipLaunchKernelGGL((issue_kernel<4>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
   }
   return hipGetLastError();

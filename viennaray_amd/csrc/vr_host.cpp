@@ -313,150 +313,17 @@ void host_orthonormal_basis(const float *v, float *basis9) {
 
 // ---------------------------------------------------------------------------
 // Disk areas clipped by the x/y walls (rayGeometryDisk.hpp:266-354 and
-// rayDiskBoundingBoxIntersector.hpp:39-432).  The four walls are visited
-// clockwise (right, bottom, left, top) like the reference; each wall is
-// described directly in world coordinates instead of through the reference's
-// swap/reflect transforms: axis, outward sign, plane coordinate, inward
-// normal, and the corner it shares with the NEXT wall.
+// rayDiskBoundingBoxIntersector.hpp:39-432): the HOST evaluation of vr_area.hpp, the source
+// the device kernel is compiled from (validation path, VR_HOST_BUILD=1).
 // ---------------------------------------------------------------------------
-namespace {
-struct Wall2D {
-  int axis;      // 0: x = W, 1: y = W
-  float sgn;     // +1 right/top, -1 left/bottom
-  float W;       // plane coordinate
-  F3 inward;     // inward unit normal
-  float cx, cy;  // "high corner" of the reference's transformed frame
-};
-
-float disk_area_inside_xy(const float *disk, const float *nrm, float lx, float ly, float hx, float hy) {
-  const float xx = disk[0], yy = disk[1], radius = disk[3];
-  F3 dn{nrm[0], nrm[1], nrm[2]};
-  normalize3(dn);
-  const float full = (float)(radius * radius * M_PI);
-  if ((lx <= xx - radius && xx + radius <= hx) && (ly <= yy - radius && yy + radius <= hy))
-    return full;
-  if ((xx + radius <= lx || hx <= xx - radius) || (yy + radius <= ly || hy <= yy - radius))
-    return 0.f;
-  const Wall2D walls[4] = {{0, 1.f, hx, F3{-1, 0, 0}, hx, hy},   // right, corner top-right
-                           {1, -1.f, ly, F3{0, 1, 0}, hx, ly},   // bottom, corner bottom-right
-                           {0, -1.f, lx, F3{1, 0, 0}, lx, ly},   // left, corner bottom-left
-                           {1, 1.f, hy, F3{0, -1, 0}, lx, hy}};  // top, corner top-left
-  float approach[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < 4; ++k) {
-    const Wall2D &w = walls[k];
-    const float c = w.sgn * disk[w.axis];   // coordinate in the wall's outward frame
-    const float H = w.sgn * w.W;
-    const float nb = w.axis == 0 ? dn.y : dn.x;
-    const float xterm = radius * std::sqrt(dn.z * dn.z + nb * nb);
-    float a;
-    if (c + xterm <= H)
-      a = std::numeric_limits<float>::max();
-    else if (c - xterm >= H)
-      a = std::numeric_limits<float>::lowest();
-    else if (xterm <= 1e-9)
-      a = std::numeric_limits<float>::max();
-    else
-      a = (H - c) * radius / xterm;
-    approach[k] = a;
-    if (a < -radius)
-      return 0.f; // fully outside (later entries stay 0 in the reference, then it returns 0)
-  }
-  float area = 0.f;
-  for (int k = 0; k < 4; ++k) {
-    const float d = approach[k];
-    if (-radius < d && d < radius) {
-      const float angle = 2 * std::acos(d / radius);
-      area += radius * radius / 2 * (angle - std::sin(angle));
-    }
-  }
-  const F3 c{disk[0], disk[1], disk[2]};
-  for (int k = 0; k < 4; ++k) {
-    const int k2 = (k + 1) % 4;
-    const float d1 = approach[k], d2 = approach[k2];
-    if (!(-radius < d1 && d1 < radius && -radius < d2 && d2 < radius))
-      continue;
-    const F3 n1 = walls[k].inward, n2 = walls[k2].inward;
-    F3 i1 = cross3(dn, n1);
-    normalize3(i1);
-    F3 i2 = cross3(dn, n2);
-    normalize3(i2);
-    if (dot3(i1, n2) >= 0)
-      i1 = F3{-i1.x, -i1.y, -i1.z};
-    if (dot3(i2, n1) >= 0)
-      i2 = F3{-i2.x, -i2.y, -i2.z};
-    const float px = walls[k2].cx, py = walls[k2].cy;
-    const F3 ip{px, py, (dn.x * c.x + dn.y * c.y + dn.z * c.z - dn.x * px - dn.y * py) / dn.z};
-    if (norm3(sub3(c, ip)) >= radius)
-      continue;
-    // The reference derives each wall's normal from a triangle spanning the wall
-    // (rayDiskBoundingBoxIntersector.hpp:124-135); on a bounding box without extent along the
-    // wall that triangle is degenerate, its normalised normal is 0/0 and the area comes out
-    // NaN (single disk, one row of disks).  Reproduced rather than "fixed".
-    auto flat = [&](const Wall2D &w) { return w.axis == 0 ? hy == ly : hx == lx; };
-    if (flat(walls[k]) || flat(walls[k2]))
-      return std::numeric_limits<float>::quiet_NaN();
-    auto circ = [&](const F3 &iDir, float d) {
-      const float ca = dot3(sub3(c, ip), iDir);
-      const F3 cp{ip.x + ca * iDir.x, ip.y + ca * iDir.y, ip.z + ca * iDir.z};
-      const float thc = std::sqrt(radius * radius - d * d);
-      return F3{cp.x + iDir.x * thc, cp.y + iDir.y * thc, cp.z + iDir.z * thc};
-    };
-    const F3 q1 = circ(i1, d1), q2 = circ(i2, d2);
-    const F3 c1 = sub3(q1, c), c2 = sub3(q2, c);
-    const float angle = std::acos(dot3(c1, c2) / norm3(c1) / norm3(c2));
-    const float seg = radius * radius / 2 * (angle - std::sin(angle));
-    const double tri = 0.5 * norm3(cross3(sub3(q1, ip), sub3(q2, ip)));
-    area = (float)(area - (seg + tri));
-  }
-  return full - area;
-}
-} // namespace
-
-void host_disk_areas(const HostGeometry &g, const int *bc2, int firstDir, int secondDir, std::vector<float> &areas) {
+void host_disk_areas(const HostGeometry &g, const AreaParams &p, std::vector<float> &areas) {
   const uint32_t n = g.numPrims;
   areas.assign(n, 0.f);
   if (g.geo != 0)
     return;
-  constexpr double eps = 1e-3;
-  const int dirs[2] = {firstDir, secondDir};
-  // rayGeometryDisk.hpp:281-284 indexes the 2-entry BC array by AXIS; axis 2 is
-  // out of range there, we use entry 1 for it.
-  auto bcAxis = [&](int axis) { return bc2[axis > 1 ? 1 : axis]; };
   parallel_ranges(n, [&](unsigned, uint32_t rb, uint32_t re) {
-  for (uint32_t i = rb; i < re; ++i) {
-    const float *disk = &g.disk4[4 * (size_t)i];
-    const float *nrm = &g.normal3[3 * (size_t)i];
-    if (g.D == 3) {
-      float a = (float)(disk[3] * disk[3] * M_PI);
-      if (bcAxis(dirs[0]) == 2 && bcAxis(dirs[1]) == 2) {
-        areas[i] = a;
-        continue;
-      }
-      if (dirs[0] != 2 && dirs[1] != 2) {
-        areas[i] = disk_area_inside_xy(disk, nrm, g.minC[0], g.minC[1], g.maxC[0], g.maxC[1]);
-        continue;
-      }
-      for (int s = 0; s < 2; ++s)
-        if (std::fabs(disk[dirs[s]] - g.minC[dirs[s]]) < eps || std::fabs(disk[dirs[s]] - g.maxC[dirs[s]]) < eps)
-          a /= 2;
-      areas[i] = a;
-    } else {
-      float a = 2 * disk[3];
-      const int ax = dirs[0];
-      for (int side = 0; side < 2; ++side) {
-        const float wallc = side ? g.maxC[ax] : g.minC[ax];
-        if (bcAxis(ax) != 2 && std::abs(disk[ax] - wallc) < disk[3]) {
-          float t = 1 - nrm[ax] * nrm[ax];
-          if (t > 1e-4) {
-            t = std::abs(disk[ax] - wallc) / std::sqrt(t);
-            if (t < disk[3])
-              a -= disk[3] - t;
-          }
-        }
-      }
-      areas[i] = a;
-    }
-  }
+    for (uint32_t i = rb; i < re; ++i)
+      areas[i] = disk_exposed_area(p, &g.disk4[4 * (size_t)i], &g.normal3[3 * (size_t)i]);
   });
 }
 

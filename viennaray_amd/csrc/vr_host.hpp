@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 
+#include "vr_area.hpp"
 #include "vr_types.hpp"
 
 namespace vr {
@@ -60,8 +61,7 @@ void host_build_walls(const float *lo, const float *hi, int firstDir, int second
 // rayUtil.hpp:287-321
 void host_orthonormal_basis(const float *v, float *basis9);
 // rayGeometryDisk.hpp:266-354 (+ rayDiskBoundingBoxIntersector.hpp)
-void host_disk_areas(const HostGeometry &g, const int *boundaryConds2, int firstDir, int secondDir,
-                     std::vector<float> &areas);
+void host_disk_areas(const HostGeometry &g, const AreaParams &p, std::vector<float> &areas);
 
 // LBVH over primitive boxes; fills bvh.nodes / bvh.order
 void host_build_bvh(const HostGeometry &g, Bvh &bvh);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "vr_area.hpp"
 #include "vr_types.hpp"
 
 namespace vr {
@@ -30,6 +31,12 @@ hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st
 hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, unsigned replicas,
                               const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, hipStream_t s);
 
+// post-processing on the device (vr_setup.hip)
+hipError_t launch_disk_areas(const float *disk4, const float *normal3, unsigned n, const AreaParams &p, float *out,
+                             hipStream_t st);
+hipError_t launch_flux_from_acc(const unsigned long long *acc, unsigned n, float *flux, hipStream_t st);
+hipError_t launch_normalize_flux(float *flux, const float *area, unsigned n, int geo, int normType, float normFactor,
+                                 double totalDiskArea, unsigned *maxOrd, hipStream_t st);
 // issue-ceiling microbenchmarks (vr_bench.hip); out: one {cycles, realtime, sink} triple of u64 per wave
 hipError_t launch_issue_kernel(int kind, unsigned blocks, unsigned iters, void *out, hipStream_t s);
 

@@ -16,6 +16,7 @@
 #include <cstring>
 
 #if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
 #define VR_HD __host__ __device__ __forceinline__
 #else
 #define VR_HD inline
@@ -154,6 +155,59 @@ VR_HD float glibc_powf(float x, float y) {
   double yy = __builtin_fma(rr, C2, 1.0);
   yy = __builtin_fma(zz, rr2, yy);
   return (float)(yy * sc);
+}
+
+// glibc 2.35 sinf (sysdeps/ieee754/flt-32/s_sinf.c) evaluates the same polynomials in the same
+// order as the sine half of sincosf: one routine serves both
+VR_HD float glibc_sinf(float y) {
+  float s, c;
+  glibc_sincosf(y, s, c);
+  return s;
+}
+
+// glibc 2.35 acosf (sysdeps/ieee754/flt-32/e_acosf.c, the fdlibm float routine; no FMA variant is
+// selected for it on x86-64).  Used by the disk-area intersector (std::acos on floats,
+// rayDiskBoundingBoxIntersector.hpp); tests/aux/libm_check.cpp compares it with the running
+// glibc on every float in [-1, 1].
+VR_HD float glibc_acosf(float x) {
+  const float one = 1.0000000000e+00f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f,
+              pio2_lo = 7.5497894159e-08f, pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f,
+              pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f, pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f,
+              qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+  const int32_t hx = (int32_t)vr_asuint(x);
+  const int32_t ix = hx & 0x7fffffff;
+  if (ix == 0x3f800000) // |x| == 1
+    return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+  if (ix > 0x3f800000)
+    return (x - x) / (x - x); // NaN
+  if (ix < 0x3f000000) { // |x| < 0.5
+    if (ix <= 0x32800000)
+      return pio2_hi + pio2_lo;
+    const float z = x * x;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    return pio2_hi - (x - (pio2_lo - x * r));
+  }
+  if (hx < 0) { // x < -0.5
+    const float z = (one + x) * 0.5f;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float s = __builtin_sqrtf(z);
+    const float r = p / q;
+    const float w = r * s - pio2_lo;
+    return pi - 2.0f * (s + w);
+  }
+  // x > 0.5
+  const float z = (one - x) * 0.5f;
+  const float s = __builtin_sqrtf(z);
+  const float df = vr_asfloat(vr_asuint(s) & 0xfffff000u);
+  const float c = (z - df * df) / (s + df);
+  const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+  const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+  const float r = p / q;
+  const float w = r * s + c;
+  return 2.0f * (df + w);
 }
 
 } // namespace vr

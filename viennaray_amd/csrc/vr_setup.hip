@@ -25,6 +25,7 @@
 
 #include <cfloat>
 
+#include "vr_area.hpp"
 #include "vr_kernels.hpp"
 #include "vr_types.hpp"
 
@@ -667,6 +668,99 @@ hipError_t launch_smooth_flux(const float *fluxIn, float *fluxOut, const float *
     return hipSuccess;
   hipLaunchKernelGGL(smooth_flux_kernel, dim3((n + 127) / 128), dim3(128), 0, st, fluxIn, fluxOut, normal3, nbOff, nbIds,
                      order, leafOfOrig, n, overflow);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Post-processing on the device: exposed disk areas
+// (computeDiskAreas + DiskBoundingBoxXYIntersector, vr_area.hpp) and normalizeFlux
+// (rayTraceDisk.hpp:103-142, rayTraceTriangle.hpp:92-130; the reference's own GPU path:
+// gpu/kernels/normKernels.cu:58-74).  One thread per primitive, caller's order.
+// ---------------------------------------------------------------------------
+__global__ void disk_areas_kernel(const float *disk4, const float *normal3, unsigned n, AreaParams p, float *out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const float4 d = reinterpret_cast<const float4 *>(disk4)[i];
+  const float disk[4] = {d.x, d.y, d.z, d.w};
+  const float nrm[3] = {normal3[3 * (size_t)i], normal3[3 * (size_t)i + 1], normal3[3 * (size_t)i + 2]};
+  out[i] = disk_exposed_area(p, disk, nrm);
+}
+
+hipError_t launch_disk_areas(const float *disk4, const float *normal3, unsigned n, const AreaParams &p, float *out,
+                             hipStream_t st) {
+  if (n == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(disk_areas_kernel, dim3((n + 127) / 128), dim3(128), 0, st, disk4, normal3, n, p, out);
+  return hipGetLastError();
+}
+
+// raw flux as the reference's float vector: float(acc * 2^-40) (acc: int64 fixed point)
+__global__ void flux_from_acc_kernel(const unsigned long long *acc, unsigned n, float *flux) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    flux[i] = (float)((double)acc[i] * 9.094947017729282379150390625e-13); // 2^-40
+}
+
+// std::max_element over the flux (ordered-uint atomicMax; NaNs never win a `<` in the reference either)
+__global__ void flux_max_kernel(const float *flux, unsigned n, unsigned *maxOrd) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  float v = i < n ? flux[i] : -FLT_MAX;
+  if (!(v == v))
+    v = -FLT_MAX;
+  for (int off = 32; off > 0; off >>= 1)
+    v = fmaxf(v, __shfl_down(v, off, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0)
+    red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(maxOrd, f2ord(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
+// SOURCE: flux *= normFactor / area (all float).  MAX, disks: flux *= (pi r^2 / area) / max in
+// double like the reference's `totalDiskArea` (a double); triangles: flux /= max * area (float).
+template <int NORM, int GEO>
+__global__ void normalize_flux_kernel(float *flux, const float *area, unsigned n, float normFactor, double totalDiskArea,
+                                      const unsigned *maxOrd) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  if (NORM == 0) {
+    flux[i] *= normFactor / area[i];
+  } else {
+    const float maxv = ord2f(*maxOrd);
+    if (GEO == 0)
+      flux[i] = (float)((double)flux[i] * ((totalDiskArea / (double)area[i]) / (double)maxv));
+    else
+      flux[i] /= maxv * area[i];
+  }
+}
+
+hipError_t launch_flux_from_acc(const unsigned long long *acc, unsigned n, float *flux, hipStream_t st) {
+  if (n == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(flux_from_acc_kernel, dim3((n + 255) / 256), dim3(256), 0, st, acc, n, flux);
+  return hipGetLastError();
+}
+
+hipError_t launch_normalize_flux(float *flux, const float *area, unsigned n, int geo, int normType, float normFactor,
+                                 double totalDiskArea, unsigned *maxOrd, hipStream_t st) {
+  if (n == 0)
+    return hipSuccess;
+  const dim3 g((n + 255) / 256), b(256);
+  if (normType == 0) {
+    hipLaunchKernelGGL((normalize_flux_kernel<0, 0>), g, b, 0, st, flux, area, n, normFactor, totalDiskArea, maxOrd);
+  } else {
+    hipError_t e = hipMemsetAsync(maxOrd, 0, 4, st); // ordered 0 = below every float
+    if (e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL(flux_max_kernel, g, b, 0, st, flux, n, maxOrd);
+    if (geo == 0)
+      hipLaunchKernelGGL((normalize_flux_kernel<1, 0>), g, b, 0, st, flux, area, n, normFactor, totalDiskArea, maxOrd);
+    else
+      hipLaunchKernelGGL((normalize_flux_kernel<1, 1>), g, b, 0, st, flux, area, n, normFactor, totalDiskArea, maxOrd);
+  }
   return hipGetLastError();
 }
 

@@ -303,6 +303,12 @@ class Trace:
         self._check(self._L.vr_normalize_flux(self._h, _fptr(f), f.size, int(norm)))
         return f
 
+    def getFluxNormalized(self, norm=NormalizationType.SOURCE):
+        """raw flux -> normalizeFlux fused on the device (one download)"""
+        out = np.empty(self._n, dtype=np.float32)
+        self._check(self._L.vr_get_flux_normalized(self._h, _fptr(out), self._n, int(norm)))
+        return out
+
     def smoothFlux(self, flux, numNeighbors=1):
         f = np.ascontiguousarray(flux, dtype=np.float32).copy()
         self._check(self._L.vr_smooth_flux(self._h, _fptr(f), f.size, int(numNeighbors)))
