@@ -474,10 +474,15 @@ SCHEDULING_KNOBS = [
     {"VR_TRACE_BLOCKS": "1"},
     {"VR_KEY_COORD": "-7.5"},
     {"VR_ABSORB_CARRY": "0"}, {"VR_ABSORB_CARRY": "1"},
+    {"VR_DEBUG_FLAGS": "128"},                        # no packet (box) queries
+    {"VR_PQ_CAND": "63", "VR_PQ_FRONTIER": "64"},     # box queries run to the end even where they do not pay
+    {"VR_PQ_CAND": "2"},                              # ... or give up half way (found hits stay valid)
+    {"VR_PQ_FRONTIER": "1"},
 ]
 
 
-@pytest.mark.parametrize("geom,sticking", [("trench3d", 0.15), ("mesh", 0.15), ("trench2d", 0.15), ("trench3d", 1.0)])
+@pytest.mark.parametrize("geom,sticking", [("trench3d", 0.15), ("mesh", 0.15), ("trench2d", 0.15), ("trench3d", 1.0),
+                                           ("plane", 0.15), ("plane", 1.0)])
 def test_scheduling_knobs_do_not_change_results(geom, sticking, monkeypatch):
     """Ray order, batching, bin geometry, packet / per-lane traversal policy, BVH leaf size and
     child order, accumulator replication: none of it may change a single accumulator bit or
@@ -496,6 +501,12 @@ def test_scheduling_knobs_do_not_change_results(geom, sticking, monkeypatch):
             t.setSourceDirection(TD.POS_Y)
             t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 2)
             t.setNumberOfRaysPerPoint(1500)
+        elif geom == "plane":  # flat scene: the box query carries every segment
+            p, n = vr.io.plane_grid(150, 0.5)
+            t = vr.TraceDisk(3)
+            t.setGeometry(p, n, 0.5)
+            t.setBoundaryConditions([BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY, BC.REFLECTIVE_BOUNDARY])
+            t.setNumberOfRaysPerPoint(12)
         else:
             gd, p, n = trench3d()
             t = vr.TraceDisk(3)

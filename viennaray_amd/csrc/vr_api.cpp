@@ -109,7 +109,10 @@ struct vr_context {
   DevBuf<float> dDisk4, dNormal3, dPoints3, dVerts, dBox, dSBox, dNodeBox;
   DevBuf<uint32_t> dTris, dBounds, dValsA, dValsB, dSortTable, dRangeLo, dRangeHi, dChildL, dChildR, dParentInt,
       dParentLeaf, dArrive, dOrder, dSubSize, dQNodes;
-  DevBuf<float> dNodesPre;
+  DevBuf<float> dNodesPre, dWide;
+  uint32_t wideRoot[3] = {0, 0, 0};  // 64-ary tree: root's first child, count | flag, primitive base
+  bool haveWide = false;
+  float sceneLo[3] = {0, 0, 0}, sceneHi[3] = {0, 0, 0};
   uint32_t numNodes = 0;         // traversal nodes emitted by the builder
   float qbase[3] = {0, 0, 0}, qscale[3] = {0, 0, 0}; // frame of the 16-byte nodes
   float keyCoord = 0.f;          // sort plane of the ray stream on the tracing axis (host_sort_plane)
@@ -437,6 +440,8 @@ static int ensure_host_neighbors(vr_context *c) {
 static int quantize_scene(vr_context *c, const float *preNodes, const float *root8) {
   const float lo[3] = {root8[0], root8[1], root8[2]}, hi[3] = {root8[4], root8[5], root8[6]};
   for (int k = 0; k < 3; ++k) {
+    c->sceneLo[k] = lo[k];
+    c->sceneHi[k] = hi[k];
     const float ext = hi[k] - lo[k];
     c->qscale[k] = ext > 0.f ? 65531.0f / ext : 0.f;
     c->qbase[k] = ext > 0.f ? lo[k] - 2.0f / c->qscale[k] : lo[k];
@@ -509,6 +514,7 @@ static int build_scene(vr_context *c) {
     VR_HIP(c, hipMemcpyAsync(c->dOrder.p, c->bvh.order.data(), (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
     VR_HIP(c, hipStreamSynchronize(c->stream));
     c->numNodes = c->bvh.numNodes;
+    c->haveWide = false; // (validation path: walks only)
     return quantize_scene(c, c->dNodes.p, c->bvh.nodes.data()); // (host builder: pre-order already)
   }
 
@@ -590,7 +596,11 @@ static int build_scene(vr_context *c) {
   s.order = c->dOrder.p;
   s.nbOff = c->dNbOff.p;
   s.nbIds = nullptr;
+  VR_HIP(c, c->dWide.ensure(wide_tree_entries(N) * 8));
+  s.wide = c->dWide.p;
   VR_HIP(c, launch_setup_bvh(s, c->dScanTmp.p, c->stream));
+  VR_HIP(c, launch_wide_tree(s, c->wideRoot, c->stream));
+  c->haveWide = true;
   // every build is verified (one small kernel; its counter is read back with the syncs below):
   // the fit's cross-workgroup hand-over is the one place the build relies on memory ordering
   VR_HIP(c, hipMemsetAsync(c->dBounds.p + 6, 0, 4, c->stream));
@@ -885,6 +895,25 @@ int vr_apply_prepare(vr_context *c) {
     p.qscale[k] = c->qscale[k];
   }
   p.prims = c->dPrims.p;
+  p.wide = c->haveWide ? c->dWide.p : nullptr;
+  p.wideTopFirst = c->wideRoot[0];
+  p.wideTopCount = c->wideRoot[1];
+  p.widePrimBase = c->wideRoot[2];
+  p.pqMaxFrontier = 12;
+  if (const char *e = std::getenv("VR_PQ_FRONTIER"))
+    p.pqMaxFrontier = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
+  p.pqMaxCand = 40;
+  if (const char *e = std::getenv("VR_PQ_CAND"))
+    p.pqMaxCand = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
+  {
+    float scale = 1e-3f;
+    for (int k = 0; k < 3; ++k) {
+      p.sceneLo[k] = c->sceneLo[k];
+      p.sceneHi[k] = c->sceneHi[k];
+      scale = std::max(scale, std::max(std::fabs(c->sceneLo[k]), std::fabs(c->sceneHi[k])));
+    }
+    p.pqPad = 1e-5f * scale; // >> the rounding of the clip (1e-7 relative); the boxes carry their own 4e-6 pad
+  }
   p.nbOff = c->dNbOff.p;
   p.nbIds = c->dNbIds.p;
   p.primSticking = dStick;
@@ -1087,7 +1116,7 @@ int vr_apply_finish(vr_context *c) {
     VR_HIP(c, hipMemcpy(dg, c->dCounters.p + 16, sizeof(dg), hipMemcpyDeviceToHost));
     static const char *names[16] = {"rounds", "walk steps", "leaf prim tests", "packet visits", "packet prim tests",
                                     "state machine", "neighbour iters", "reflect iters", "refill reps", "wall init",
-                                    "roulette", "credit", "-", "-", "-", "-"};
+                                    "roulette", "credit", "pq attempts", "pq done", "-", "-"};
     for (int k = 0; k < 16; ++k)
       if (dg[2 * k])
         std::fprintf(stderr, "diag %-18s wave-iters %12llu  lane-iters %14llu  (%.1f lanes)\n", names[k], dg[2 * k],

@@ -31,6 +31,9 @@ hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st
 hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, unsigned replicas,
                               const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, hipStream_t s);
 
+// 64-ary box tree for the packet query (vr_setup.hip)
+size_t wide_tree_entries(unsigned n);
+hipError_t launch_wide_tree(const SetupParams &s, unsigned *out3, hipStream_t st);
 // post-processing on the device (vr_setup.hip)
 hipError_t launch_disk_areas(const float *disk4, const float *normal3, unsigned n, const AreaParams &p, float *out,
                              hipStream_t st);

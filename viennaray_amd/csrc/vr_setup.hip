@@ -764,6 +764,98 @@ hipError_t launch_normalize_flux(float *flux, const float *area, unsigned n, int
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// 64-ary box tree over the Morton-sorted primitives (packet query): a lowest-level node = union of
+// the padded boxes of 64 consecutive primitives, a node of level l+1 = union of 64 consecutive nodes of level l.
+// Implicit topology (children are contiguous), so there is nothing to sort or link; the
+// Morton order makes 64 consecutive primitives a compact patch.  Stored top level first.
+// ---------------------------------------------------------------------------
+// lowest level: a node = 64 consecutive primitives (children implicit: leaf positions first .. first+cnt-1)
+__global__ void wide_leafnodes_kernel(const float *sbox, unsigned n, float4 *wide, unsigned nodeBase,
+                                      unsigned nodeCount) {
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nodeCount)
+    return;
+  const unsigned first = 64u * g;
+  const unsigned cnt = min(64u, n - first);
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (unsigned k = 0; k < cnt; ++k) {
+    const float *b = sbox + 6 * (size_t)(first + k);
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = fminf(lo[c], b[c]);
+      hi[c] = fmaxf(hi[c], b[3 + c]);
+    }
+  }
+  wide[2 * (size_t)(nodeBase + g)] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(first));
+  wide[2 * (size_t)(nodeBase + g) + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(cnt | VR_WIDE_PRIMS));
+}
+
+__global__ void wide_level_kernel(float4 *wide, unsigned childBase, unsigned childCount, unsigned nodeBase,
+                                  unsigned nodeCount) {
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nodeCount)
+    return;
+  const unsigned first = childBase + 64u * g;
+  const unsigned cnt = min(64u, childCount - 64u * g);
+  float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (unsigned k = 0; k < cnt; ++k) {
+    const float4 a = wide[2 * (size_t)(first + k)], b = wide[2 * (size_t)(first + k) + 1];
+    lo[0] = fminf(lo[0], a.x);
+    lo[1] = fminf(lo[1], a.y);
+    lo[2] = fminf(lo[2], a.z);
+    hi[0] = fmaxf(hi[0], b.x);
+    hi[1] = fmaxf(hi[1], b.y);
+    hi[2] = fmaxf(hi[2], b.z);
+  }
+  wide[2 * (size_t)(nodeBase + g)] = make_float4(lo[0], lo[1], lo[2], __uint_as_float(first));
+  wide[2 * (size_t)(nodeBase + g) + 1] = make_float4(hi[0], hi[1], hi[2], __uint_as_float(cnt));
+}
+
+// entries the tree of n primitives needs (levels above the primitives)
+size_t wide_tree_entries(unsigned n) {
+  size_t total = 0, c = n;
+  do {
+    c = (c + 63) / 64;
+    total += c;
+  } while (c > 64);
+  return total + 1;
+}
+
+// builds the tree from s.sbox (sorted, padded boxes); out3 = the root's {first child entry,
+// child count | VR_WIDE_PRIMS if the root's children are the primitives themselves, 0}
+hipError_t launch_wide_tree(const SetupParams &s, unsigned *out3, hipStream_t st) {
+  const unsigned n = s.n;
+  out3[0] = out3[1] = out3[2] = 0;
+  if (n == 0)
+    return hipSuccess;
+  if (n <= 64) { // the root's children are the primitives
+    out3[1] = n | VR_WIDE_PRIMS;
+    return hipSuccess;
+  }
+  unsigned counts[8], nl = 0;
+  counts[nl++] = (n + 63) / 64;
+  while (counts[nl - 1] > 64) {
+    counts[nl] = (counts[nl - 1] + 63) / 64;
+    ++nl;
+  }
+  // memory order: top level first
+  unsigned base[8];
+  unsigned off = 0;
+  for (int l = (int)nl - 1; l >= 0; --l) {
+    base[l] = off;
+    off += counts[l];
+  }
+  float4 *wide = reinterpret_cast<float4 *>(s.wide);
+  hipLaunchKernelGGL(wide_leafnodes_kernel, dim3((counts[0] + 63) / 64), dim3(64), 0, st, s.sbox, n, wide, base[0],
+                     counts[0]);
+  for (unsigned l = 1; l < nl; ++l)
+    hipLaunchKernelGGL(wide_level_kernel, dim3((counts[l] + 63) / 64), dim3(64), 0, st, wide, base[l - 1], counts[l - 1],
+                       base[l], counts[l]);
+  out3[0] = base[nl - 1];
+  out3[1] = counts[nl - 1];
+  return hipGetLastError();
+}
+
 hipError_t launch_quantize_nodes(const float *nodes, unsigned numNodes, const float *base3, const float *scale3,
                                  uint32_t *qnodes, hipStream_t st) {
   if (numNodes == 0)

@@ -313,6 +313,7 @@ trace_kernel(const TraceParams p) {
   __shared__ float wallS[96];
   // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
   __shared__ unsigned cntS[8 * VR_BLOCK];
+  __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier / candidate lists
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
@@ -360,6 +361,7 @@ trace_kernel(const TraceParams p) {
   unsigned curBin = 0, spanStart = 0, spanEnd = 0, curOff = 0, curCnt = 0, curBase = 0;
   unsigned spanCounts = 0; // lane i: ray count of bin spanStart + i
   unsigned packetSkip = 0, packetFails = 0; // wave-uniform back-off of packet attempts
+  unsigned pqSkip = 0, pqFails = 0;         // ... and of packet-query attempts
   bool exhausted = false;
   VR_DIAG_DECL
 
@@ -460,7 +462,26 @@ trace_kernel(const TraceParams p) {
     const bool usePacket =
         !(p.debugFlags & 32u) && carried == 0ull && packetSkip == 0 && __popcll(ballot64(active)) >= 8;
     bool packetDone = false;
-    if (usePacket) {
+    if (usePacket && p.wide && !(p.debugFlags & 128u)) {
+      // first choice: the box query (one wide-tree search for the whole wave)
+      if (pqSkip == 0) {
+        if (active) {
+          DIAG(12);
+        }
+        packetDone = pq_hit_packet<GEO>(p, active, org, dir, tnear, h, pqS + (tid >> 6) * 128u VR_DIAG_PASS);
+        pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
+        pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;
+        if (packetDone) {
+          node = VR_END;
+          if (active) {
+            DIAG(13);
+          }
+        }
+      } else {
+        --pqSkip;
+      }
+    }
+    if (usePacket && !packetDone) {
       packetDone = bvh_hit_packet<GEO>(p, active, org, dir, tnear, h, p.packetBudget, p.packetRatio VR_DIAG_PASS);
       // a wave whose rays have scattered stops paying for hopeless packets for a while
       packetFails = packetDone ? 0u : (packetFails < 6u ? packetFails + 1u : 6u);
@@ -637,7 +658,7 @@ trace_kernel(const TraceParams p) {
   }
 
 #ifdef VR_DIAG
-  for (int k = 0; k < 12; ++k) {
+  for (int k = 0; k < 16; ++k) {
     const unsigned long long sw = wave_sum(diagW[k]), sl = wave_sum(diagL[k]);
     if (lane == 0 && sl) {
       atomicAdd(&p.counters[16 + 2 * k], sw);

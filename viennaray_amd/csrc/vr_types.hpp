@@ -14,7 +14,8 @@ constexpr uint32_t VR_LEAF = 0x80000000u;
 constexpr uint32_t VR_END = 0xFFFFFFFFu;
 constexpr uint32_t VR_LEAF_FIRST_MASK = (1u << 27) - 1;
 constexpr int VR_LEAF_MAX = 4;
-constexpr uint32_t VR_QEND = 0x7FFFFFFFu; // "no escape" in a 16-byte node (bit 31 is the leaf flag)
+constexpr uint32_t VR_QEND = 0x7FFFFFFFu;
+constexpr uint32_t VR_WIDE_PRIMS = 0x80000000u; // wide-tree node: its children are primitive boxes // "no escape" in a 16-byte node (bit 31 is the leaf flag)
 
 // Primitive records, stored in BVH-leaf (Morton) order so a leaf is one
 // contiguous, coalescable run:
@@ -42,6 +43,15 @@ struct TraceParams {
   uint32_t numNodes;
   float qbase[3], qscale[3];  // quantised coordinate = (x - qbase) * qscale
   const float *prims;         // float4 records
+  // 64-ary box tree over the primitives in leaf order (packet query, vr_device.hpp: pq_hit_packet):
+  // entries of two float4 {lo.xyz, bits(first child)} {hi.xyz, bits(child count | VR_WIDE_PRIMS)};
+  // children of a VR_WIDE_PRIMS node are the primitives at leaf positions first .. first + count - 1
+  const float *wide;
+  uint32_t wideTopFirst, wideTopCount; // the root's children (count carries VR_WIDE_PRIMS if they are primitives)
+  uint32_t widePrimBase;
+  uint32_t pqMaxFrontier, pqMaxCand;   // give-up thresholds of the packet query
+  float sceneLo[3], sceneHi[3];        // root box of the BVH (every padded primitive box)
+  float pqPad;                         // outward padding of the packet's box (float rounding of the clip)
   const uint32_t *nbOff;      // [numPrims+1], disk neighbourhood CSR (leaf order)
   const uint32_t *nbIds;      // leaf positions
   const float *primSticking;  // optional [numPrims] (leaf order) or nullptr
@@ -116,6 +126,7 @@ struct SetupParams {
   float *prims;
   uint32_t *leafOfOrig, *order;
   uint32_t *nbOff, *nbIds;
+  float *wide;            // 64-ary box tree (see TraceParams::wide), (n + n/64 + ...) x 8 floats
 };
 
 // counters[] slots
