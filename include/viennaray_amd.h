@@ -42,8 +42,13 @@ enum { VR_REFLECTIVE_BOUNDARY = 0, VR_PERIODIC_BOUNDARY = 1, VR_IGNORE_BOUNDARY 
 enum { VR_POS_X = 0, VR_NEG_X = 1, VR_POS_Y = 2, VR_NEG_Y = 3, VR_POS_Z = 4, VR_NEG_Z = 5 };
 /* rayUtil.hpp:38 */
 enum { VR_NORM_SOURCE = 0, VR_NORM_MAX = 1 };
-/* built-in particle kinds (rayParticle.hpp:126-204) */
-enum { VR_PARTICLE_DIFFUSE = 0, VR_PARTICLE_SPECULAR = 1 };
+/* particle kinds of the device registry (viennaray_amd/csrc/vr_particles.hpp):
+ * 0, 1     the reference's built-ins DiffuseParticle / SpecularParticle (rayParticle.hpp:126-204)
+ * 2        CONED_COSINE: surfaceReflection = ReflectionConedCosine(coneAngle) (rayReflection.hpp:52-120),
+ *          collision like SpecularParticle
+ * 3        DIFFUSE_COSINE: a DiffuseParticle with TWO data labels: label 0 += w, label 1 += w * max(0, -d.n)
+ * A user model is added to the registry (a struct of __device__ functions) and gets the next id. */
+enum { VR_PARTICLE_DIFFUSE = 0, VR_PARTICLE_SPECULAR = 1, VR_PARTICLE_CONED_COSINE = 2, VR_PARTICLE_DIFFUSE_COSINE = 3 };
 /* geometry kinds (rayGeometry.hpp:9) */
 enum { VR_GEOMETRY_DISK = 0, VR_GEOMETRY_TRIANGLE = 1 };
 
@@ -77,6 +82,8 @@ typedef struct vr_particle {
   int32_t numMaterialSticking;      /* 0 = none                               */
   const int32_t *materialIds;       /* [numMaterialSticking] material id ...  */
   const float *materialSticking;    /* ... -> sticking override               */
+  float coneAngle;                  /* CONED_COSINE: maxConeAngle in radians  */
+  float meanFreePath;               /* getMeanFreePath(); <= 0: no scattering (rayParticle.hpp:113) */
 } vr_particle;
 
 /* ---- life cycle (Trace::Trace / ~Trace, rayTrace.hpp:17-29) ------------- */
@@ -106,6 +113,15 @@ int vr_set_boundary_conditions(vr_context *ctx, const int32_t *bcs, int n /* = D
 int vr_set_source_direction(vr_context *ctx, int traceDirection);
 int vr_set_primary_direction(vr_context *ctx, const float *dir3 /* NULL = off */);
 int vr_set_particle(vr_context *ctx, const vr_particle *particle);
+/* VIENNARAY_USE_WDIST (CMakeLists.txt:15, rayTraceKernel.hpp:258-296) as a run-time switch: a hit's
+ * weight is shared among the credited disks by inverse impact distance                       */
+int vr_set_use_wdist(vr_context *ctx, int on);
+/* setSource(SourceGrid) (raySourceGrid.hpp): explicit origins, direction from the particle's cosine
+ * power; numRays = n * numRaysPerPoint.  n == 0 = resetSource() (rayTrace.hpp:53-61)            */
+int vr_set_source_grid(vr_context *ctx, const float *points3, uint32_t n);
+/* setSource(any other Source) (raySource.hpp:10-19): the facade runs the callback on the host and
+ * hands over ray idx -> origin, direction, engine outputs consumed.  n == 0 = resetSource()      */
+int vr_set_host_rays(vr_context *ctx, const float *org3, const float *dir3, const uint32_t *draws, uint64_t n);
 int vr_set_number_of_rays_per_point(vr_context *ctx, uint64_t n);
 int vr_set_number_of_rays_fixed(vr_context *ctx, uint64_t n);
 int vr_set_max_reflections(vr_context *ctx, uint32_t n);
@@ -136,6 +152,10 @@ uint32_t vr_num_primitives(const vr_context *ctx);
 /* getLocalData().getVectorData(0) (rayTrace.hpp:135): raw, un-normalised     */
 int vr_get_flux(vr_context *ctx, float *out, uint32_t n);
 int vr_get_flux_f64(vr_context *ctx, double *out, uint32_t n);
+/* getLocalData().getVectorData(dataIdx) for particles with several data labels
+ * (AbstractParticle::getLocalDataLabels, rayParticle.hpp:75-78; rayTraceDisk.hpp:40-47)      */
+uint32_t vr_num_data(const vr_context *ctx);
+int vr_get_flux_data(vr_context *ctx, uint32_t dataIdx, float *out, uint32_t n);
 int vr_get_trace_info(const vr_context *ctx, vr_trace_info *out);
 /* which trace_kernel variant the last vr_apply_prepare selected: 0 general (reflection, roulette,
  * RNG), 1 absorbing + flat scene, 2 absorbing + structured scene             */

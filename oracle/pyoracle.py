@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvr_oracle.so")
 
-DIFFUSE, SPECULAR = 0, 1
+DIFFUSE, SPECULAR, CONED_COSINE, DIFFUSE_COSINE = 0, 1, 2, 3
 REFLECTIVE, PERIODIC, IGNORE = 0, 1, 2
 POS_X, NEG_X, POS_Y, NEG_Y, POS_Z, NEG_Z = range(6)
 
@@ -48,6 +48,15 @@ def lib():
         L.orc_set_source_direction.argtypes = [vp, C.c_int]
         L.orc_set_primary_direction.argtypes = [vp, fp]
         L.orc_set_particle.argtypes = [vp, C.c_int, C.c_float, C.c_float]
+        L.orc_set_particle_ex.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.orc_set_material_sticking.argtypes = [vp, C.POINTER(C.c_int), fp, C.c_int]
+        L.orc_set_wdist.argtypes = [vp, C.c_int]
+        L.orc_set_source_grid.argtypes = [vp, fp, C.c_uint]
+        L.orc_create_source_grid.argtypes = [vp, C.c_uint64, C.c_float, fp, C.c_uint]
+        L.orc_create_source_grid.restype = C.c_uint
+        L.orc_num_data.argtypes = [vp]
+        L.orc_num_data.restype = C.c_int
+        L.orc_get_flux_data.argtypes = [vp, C.c_int, fp]
         L.orc_set_num_rays_per_point.argtypes = [vp, C.c_uint64]
         L.orc_set_num_rays_fixed.argtypes = [vp, C.c_uint64]
         L.orc_set_max_reflections.argtypes = [vp, C.c_uint]
@@ -186,6 +195,37 @@ class Oracle:
 
     def set_particle(self, kind, sticking, source_power=1.0):
         self.L.orc_set_particle(self.h, kind, sticking, source_power)
+
+    def set_particle_ex(self, kind, sticking, source_power=1.0, cone_angle=0.0, mean_free_path=-1.0):
+        self.L.orc_set_particle_ex(self.h, kind, sticking, source_power, cone_angle, mean_free_path)
+
+    def set_material_sticking(self, mapping):
+        ids = (C.c_int * len(mapping))(*mapping.keys())
+        vals = (C.c_float * len(mapping))(*mapping.values())
+        self.L.orc_set_material_sticking(self.h, ids, vals, len(mapping))
+
+    def set_wdist(self, on=True):
+        self.L.orc_set_wdist(self.h, int(on))
+
+    def set_source_grid(self, pts):
+        if pts is None:
+            self.L.orc_set_source_grid(self.h, None, 0)
+        else:
+            a = _f32(pts).reshape(-1, 3)
+            self.L.orc_set_source_grid(self.h, _fp(a), a.shape[0])
+
+    def create_source_grid(self, num_points, grid_delta):
+        out = np.empty((int(num_points) * 2 + 64, 3), dtype=np.float32)
+        n = self.L.orc_create_source_grid(self.h, int(num_points), grid_delta, _fp(out), out.shape[0])
+        return out[:n].copy()
+
+    def num_data(self):
+        return self.L.orc_num_data(self.h)
+
+    def flux_data(self, idx):
+        out = np.empty(self.n, dtype=np.float32)
+        self.L.orc_get_flux_data(self.h, idx, _fp(out))
+        return out
 
     def set_num_rays_per_point(self, n):
         self.L.orc_set_num_rays_per_point(self.h, n)

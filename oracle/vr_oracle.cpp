@@ -169,7 +169,11 @@ private:
 // ----------------------------------------------------------------------------
 enum TraceDirection { POS_X = 0, NEG_X, POS_Y, NEG_Y, POS_Z, NEG_Z };
 enum BoundaryCondition { REFLECTIVE = 0, PERIODIC = 1, IGNORE = 2 };
-enum ParticleKind { DIFFUSE = 0, SPECULAR = 1 };
+// DIFFUSE / SPECULAR: rayParticle.hpp:126-204.  CONED_COSINE and DIFFUSE_COSINE are plug-in particles
+// written against AbstractParticle the way a user (ViennaPS) writes them: CONED_COSINE reflects
+// with ReflectionConedCosine (rayReflection.hpp:52-120) and collects like SpecularParticle;
+// DIFFUSE_COSINE is a DiffuseParticle with TWO data labels: label 0 += w, label 1 += w * max(0, -d.n)
+enum ParticleKind { DIFFUSE = 0, SPECULAR = 1, CONED_COSINE = 2, DIFFUSE_COSINE = 3 };
 enum GeoType { DISK = 0, TRIANGLE = 1 };
 
 struct TraceInfo {
@@ -724,6 +728,15 @@ struct Context {
   int particleKind = DIFFUSE;
   float sticking = 1.f;
   float sourcePower = 1.f;
+  // particle plug-ins beyond the two built-ins: what a user-defined
+  // AbstractParticle (rayParticle.hpp:21-81) typically overrides
+  float coneAngle = 0.f;    // CONED: surfaceReflection = ReflectionConedCosine(maxConeAngle)
+  float meanFreePath = -1.f; // getMeanFreePath(); <= 0: no scattering (rayParticle.hpp:113)
+  std::vector<std::pair<int, float>> materialSticking; // gpu::Particle::materialSticking (rayParticle.hpp:208-218)
+  bool useWdist = false;    // VIENNARAY_USE_WDIST (rayTraceKernel.hpp:258-296), a run-time switch here
+  // alternative source (raySourceGrid.hpp): 0 = SourceRandom, 1 = SourceGrid
+  int sourceKind = 0;
+  std::vector<Vec3> sourceGrid;
   // KernelConfig (rayUtil.hpp:83-94)
   uint64_t numRaysPerPoint = 1000, numRaysFixed = 0;
   unsigned maxReflections = std::numeric_limits<unsigned>::max();
@@ -744,8 +757,9 @@ struct Context {
   float sourceArea = 0.f;
   uint64_t numRaysLast = 0;
 
-  std::vector<float> flux;
+  std::vector<float> flux; // numData() vectors of numPrims, one after the other
   TraceInfo info;
+  int numData() const { return particleKind == DIFFUSE_COSINE ? 2 : 1; }
 
   // optional event log (first `evCap` events over the traced range)
   struct Event {
@@ -1002,6 +1016,58 @@ static inline Vec3 ReflectionDiffuse(int D, const Vec3 &n, RNG &rng) {
   return r;
 }
 
+// rayReflection.hpp:52-120
+template <class RNG>
+static inline Vec3 ReflectionConedCosine(int D, const Vec3 &rayDir, const Vec3 &geomNormal, RNG &rng,
+                                         const float maxConeAngle) {
+  std::uniform_real_distribution<double> rand01(0.0, 1.0);
+  if (maxConeAngle <= 0.f)
+    return ReflectionSpecular(rayDir, geomNormal);
+  if (maxConeAngle >= M_PI_2)
+    return ReflectionDiffuse(D, geomNormal, rng);
+  // specular direction (w)
+  const Vec3 v = Inv(rayDir);
+  const float f = 2.f * DotProduct(geomNormal, v);
+  Vec3 w{f * geomNormal[0] - v[0], f * geomNormal[1] - v[1], f * geomNormal[2] - v[2]};
+  Normalize(w);
+  // fast ONB around w (Frisvad)
+  Vec3 t, b;
+  if (w[2] < -0.999999f) {
+    t = Vec3{0.f, -1.f, 0.f};
+    b = Vec3{-1.f, 0.f, 0.f};
+  } else {
+    const float a = 1.f / (1.f + w[2]);
+    const float bx = -w[0] * w[1] * a, by = 1.f - w[1] * w[1] * a;
+    t = Vec3{1.f - w[0] * w[0] * a, bx, -w[0]};
+    b = Vec3{bx, by, -w[1]};
+  }
+  // sample polar angle (accept-reject)
+  double theta;
+  for (;;) {
+    const double u = std::sqrt(rand01(rng));
+    const double s = std::sqrt(std::max(1.0 - u, 0.0));
+    theta = maxConeAngle * s;
+    const double rhs = std::cos(M_PI_2 * s) * std::sin(theta);
+    if (rand01(rng) * theta * u <= rhs)
+      break;
+  }
+  const float sinT = std::sin(theta);
+  const float cosT = std::cos(theta);
+  const double phi = 2.0 * M_PI * rand01(rng);
+  float sinP = std::sin(phi), cosP = std::cos(phi);
+  Vec3 dir{sinT * (cosP * t[0] + sinP * b[0]) + cosT * w[0], sinT * (cosP * t[1] + sinP * b[1]) + cosT * w[1],
+           sinT * (cosP * t[2] + sinP * b[2]) + cosT * w[2]};
+  const float dp = DotProduct(dir, geomNormal);
+  if (dp <= 0.f) {
+    const float g = 2.f * dp;
+    dir = Vec3{dir[0] - g * geomNormal[0], dir[1] - g * geomNormal[1], dir[2] - g * geomNormal[2]};
+  }
+  if (D == 2)
+    dir[2] = 0.f;
+  Normalize(dir);
+  return dir;
+}
+
 // rayBoundary.hpp:155-162
 static inline Vec3 getNewOrigin(const Ray &ray, float tfar) {
   return Vec3{ray.org[0] + ray.dir[0] * tfar, ray.org[1] + ray.dir[1] * tfar,
@@ -1056,7 +1122,7 @@ static void boundaryProcessHit(const Context &c, Ray &ray, float tfar,
 
 // rayTraceKernel.hpp:462-507
 static bool checkLocalIntersection(const Context &c, const Ray &ray,
-                                   unsigned primID) {
+                                   unsigned primID, float *impactDistance = nullptr) {
   const Vec3 ro{ray.org[0], ray.org[1], ray.org[2]};
   const Vec3 rd{ray.dir[0], ray.dir[1], ray.dir[2]};
   const Vec3 &normal = c.normals[primID];
@@ -1075,10 +1141,64 @@ static bool checkLocalIntersection(const Context &c, const Ray &ray,
   for (int i = 0; i < 3; ++i)
     hp[i] = hp[i] - diskOrigin[i];
   float distance = sqrtf(DotProduct(hp, hp));
+  if (impactDistance)
+    *impactDistance = distance;
   return disk[3] > distance;
 }
 
 // raySourceRandom.hpp:50-116
+// raySourceGrid.hpp:25-66: origin = grid[idx % numPoints], direction from two draws
+template <class RNG>
+static void sourceGridSample(const Context &c, long long idx, RNG &rng, Vec3 &origin, Vec3 &direction) {
+  const int rayDir = c.ts[0], firstDir = c.ts[1], secondDir = c.ts[2];
+  const float posNeg = (float)c.ts[4];
+  const float ee = 2.f / (c.sourcePower + 1); // raySourceGrid.hpp:22
+  origin = c.sourceGrid[(size_t)idx % c.sourceGrid.size()];
+  direction = Vec3{0.f, 0.f, 0.f};
+  std::uniform_real_distribution<float> uniDist;
+  auto r1 = uniDist(rng);
+  auto r2 = uniDist(rng);
+  float tt = pow(r2, ee);
+  direction[rayDir] = posNeg * sqrtf(tt);
+  direction[firstDir] = cosf(M_PI * 2.f * r1) * sqrtf(1.f - tt);
+  if (c.D == 2)
+    direction[secondDir] = 0;
+  else
+    direction[secondDir] = sinf(M_PI * 2.f * r1) * sqrtf(1.f - tt);
+  Normalize(direction);
+}
+
+// rayUtil.hpp:564-611
+static std::vector<Vec3> createSourceGrid(int D, const std::array<Vec3, 2> &bdBox, size_t numPoints, float gridDelta,
+                                          const std::array<int, 5> &ts) {
+  std::vector<Vec3> grid;
+  grid.reserve(numPoints);
+  constexpr double eps = 1e-4;
+  const int rayDir = ts[0], firstDir = ts[1], secondDir = ts[2], minMax = ts[3];
+  auto len1 = bdBox[1][firstDir] - bdBox[0][firstDir];
+  auto len2 = bdBox[1][secondDir] - bdBox[0][secondDir];
+  auto numPointsInFirstDir = static_cast<size_t>(round(len1 / gridDelta));
+  auto numPointsInSecondDir = static_cast<size_t>(round(len2 / gridDelta));
+  const unsigned long ratio = numPointsInFirstDir / numPointsInSecondDir;
+  numPointsInFirstDir = static_cast<size_t>(std::sqrt(numPoints * ratio));
+  numPointsInSecondDir = static_cast<size_t>(std::sqrt(numPoints / ratio));
+  auto firstGridDelta = (len1 - 2 * eps) / static_cast<float>(numPointsInFirstDir - 1);
+  auto secondGridDelta = (len2 - 2 * eps) / static_cast<float>(numPointsInSecondDir - 1);
+  Vec3 point{0.f, 0.f, 0.f};
+  point[rayDir] = bdBox[minMax][rayDir];
+  for (auto uu = bdBox[0][secondDir] + eps; uu <= bdBox[1][secondDir] - eps; uu += secondGridDelta) {
+    if (D == 2)
+      point[secondDir] = 0.;
+    else
+      point[secondDir] = uu;
+    for (auto vv = bdBox[0][firstDir] + eps; vv <= bdBox[1][firstDir] - eps; vv += firstGridDelta) {
+      point[firstDir] = vv;
+      grid.push_back(point);
+    }
+  }
+  return grid;
+}
+
 template <class RNG>
 static void sourceSample(const Context &c, RNG &rng, Vec3 &origin, Vec3 &direction) {
   const int rayDir = c.ts[0], firstDir = c.ts[1], secondDir = c.ts[2],
@@ -1163,7 +1283,10 @@ static void traceRay(Context &c, long long idx, unsigned seed, float *flux,
   {
     // initNew: no draws; initNewWithDirection: returns 0 (rayParticle.hpp:91-94)
     Vec3 o, d;
-    sourceSample(c, rngState, o, d);
+    if (c.sourceKind == 1)
+      sourceGridSample(c, idx, rngState, o, d);
+    else
+      sourceSample(c, rngState, o, d);
     fillRayPosition(ray, o);
     rayDirection = d;
     fillRayDirection(D, ray, rayDirection);
@@ -1186,8 +1309,24 @@ static void traceRay(Context &c, long long idx, unsigned seed, float *flux,
       log(0, ~0u, 0.f, rayWeight);
       break;
     }
-    // mean-free-path scatter (rayTraceKernel.hpp:179-203): lambda = -1 for the
-    // built-in particles (rayParticle.hpp:113) -> dead branch.
+    // mean-free-path scatter (rayTraceKernel.hpp:179-203), quirk Q1 kept: the origin moves by
+    // dir * rnd (the uniform number itself) and the test comes after the closest hit was found
+    if (c.meanFreePath > 0.f) {
+      std::uniform_real_distribution<float> dist(0., 1.);
+      float scatterProbability = 1. - std::exp(-tfar / c.meanFreePath);
+      auto rnd = dist(rngState);
+      if (rnd < scatterProbability) {
+        const Vec3 origin{static_cast<float>(ray.org[0] + ray.dir[0] * rnd),
+                          static_cast<float>(ray.org[1] + ray.dir[1] * rnd),
+                          static_cast<float>(ray.org[2] + ray.dir[2] * rnd)};
+        rayDirection = pickRandomPointOnUnitSphere(rngState);
+        fillRayPosition(ray, origin);
+        fillRayDirection(D, ray, rayDirection);
+        ++cnt.particleHits;
+        reflect = true;
+        continue;
+      }
+    }
 
     if (hit.geomID == BOUNDARY_ID) {
       if (++boundaryHits > c.maxBoundaryHits) {
@@ -1225,24 +1364,60 @@ static void traceRay(Context &c, long long idx, unsigned seed, float *flux,
 
     ++cnt.geoHits;
     log(3, hit.primID, tfar, rayWeight);
+    // surfaceCollision of the particle (rayParticle.hpp:148-156 and the plug-ins above)
+    const unsigned N = c.numPrims;
+    auto collide = [&](float w, unsigned id) {
+      flux[id] += w;
+      if (c.particleKind == DIFFUSE_COSINE) {
+        const float cosTheta = -DotProduct(rayDirection, c.normals[id]);
+        flux[N + id] += w * std::max(cosTheta, 0.f);
+      }
+    };
     if (c.geoType == DISK) {
-      // surfaceCollision for the closest disk, then every overlapping neighbour
-      flux[hit.primID] += rayWeight;
-      for (unsigned id : c.neighbors[hit.primID])
-        if (checkLocalIntersection(c, ray, id))
-          flux[id] += rayWeight;
+      // the closest disk, then every overlapping neighbour (rayTraceKernel.hpp:255-300)
+      unsigned hitIds[64];
+      float dists[64];
+      unsigned numHit = 0;
+      hitIds[numHit] = hit.primID;
+      dists[numHit++] = Distance(hitPoint, Vec3{c.disks[hit.primID][0], c.disks[hit.primID][1], c.disks[hit.primID][2]}) + 1e-6f;
+      for (unsigned id : c.neighbors[hit.primID]) {
+        float distance;
+        if (checkLocalIntersection(c, ray, id, &distance) && numHit < 64) {
+          hitIds[numHit] = id;
+          dists[numHit++] = distance + 1e-6f;
+        }
+      }
+      float invDistanceWeightSum = 0;
+      if (c.useWdist)
+        for (unsigned k = 0; k < numHit; ++k)
+          invDistanceWeightSum += 1 / dists[k];
+      for (unsigned k = 0; k < numHit; ++k) {
+        float distRayWeight = rayWeight;
+        if (c.useWdist) // rayTraceKernel.hpp:291-294
+          distRayWeight = rayWeight / dists[k] / invDistanceWeightSum * numHit;
+        collide(distRayWeight, hitIds[k]);
+      }
     } else {
-      flux[hit.primID] += rayWeight;
+      collide(rayWeight, hit.primID);
     }
 
     // surfaceReflection (rayParticle.hpp:137-146,178-187) — called even when
     // sticking == 1
     Vec3 newDir;
-    if (c.particleKind == DIFFUSE)
+    if (c.particleKind == DIFFUSE || c.particleKind == DIFFUSE_COSINE)
       newDir = ReflectionDiffuse(D, geomNormal, rngState);
+    else if (c.particleKind == CONED_COSINE)
+      newDir = ReflectionConedCosine(D, rayDirection, geomNormal, rngState, c.coneAngle);
     else
       newDir = ReflectionSpecular(rayDirection, geomNormal);
-    const float sticking = c.sticking;
+    // sticking by the material of the CLOSEST primitive (rayTraceKernel.hpp:310-313)
+    float sticking = c.sticking;
+    if (!c.materialSticking.empty()) {
+      const int mat = hit.primID < c.materialIds.size() ? c.materialIds[hit.primID] : 0;
+      for (const auto &ms : c.materialSticking)
+        if (ms.first == mat)
+          sticking = ms.second;
+    }
 
     rayWeight -= rayWeight * sticking;
     if (rayWeight <= 0)
@@ -1336,8 +1511,10 @@ static void apply(Context &c, int numThreads) {
   }
   if (c.geoType == DISK && c.diskRadius > c.gridDelta)
     c.info.warning = 1;
+  // rayTraceKernel.hpp:57-61: numRaysFixed, or source.getNumPoints() * numRaysPerPoint
+  const long long srcPoints = c.sourceKind == 1 ? (long long)c.sourceGrid.size() : (long long)c.numPrims;
   const long long numRays =
-      c.numRaysFixed == 0 ? (long long)c.numPrims * (long long)c.numRaysPerPoint
+      c.numRaysFixed == 0 ? srcPoints * (long long)c.numRaysPerPoint
                           : (long long)c.numRaysFixed;
   c.numRaysLast = numRays;
   long long first = 0, last = numRays;
@@ -1353,7 +1530,8 @@ static void apply(Context &c, int numThreads) {
     seed = (unsigned)rd();
   }
   const unsigned N = c.numPrims;
-  std::vector<std::vector<float>> tl(numThreads, std::vector<float>(N, 0.f));
+  const unsigned ND = (unsigned)c.numData();
+  std::vector<std::vector<float>> tl(numThreads, std::vector<float>((size_t)N * ND, 0.f));
   std::vector<Counters> tc(numThreads);
   c.events.clear();
   auto t0 = std::chrono::steady_clock::now();
@@ -1376,8 +1554,8 @@ static void apply(Context &c, int numThreads) {
   }
   auto t1 = std::chrono::steady_clock::now();
   // merge (rayTraceKernel.hpp:348-360): local[j] += tl[k][j], k ascending
-  c.flux.assign(N, 0.f);
-  for (unsigned j = 0; j < N; ++j)
+  c.flux.assign((size_t)N * ND, 0.f);
+  for (size_t j = 0; j < (size_t)N * ND; ++j)
     for (int k = 0; k < numThreads; ++k)
       c.flux[j] += tl[k][j];
   Counters s;
@@ -1502,6 +1680,40 @@ void orc_set_particle(Context *c, int kind, float sticking, float sourcePower) {
   // DiffuseParticle::getSourceDistributionPower() == 1 (rayParticle.hpp:158)
   c->sourcePower = kind == orc::DIFFUSE ? 1.f : sourcePower;
 }
+// plug-in particles: kind (orc::ParticleKind), sticking, source power, cone angle, mean free path
+void orc_set_particle_ex(Context *c, int kind, float sticking, float sourcePower, float coneAngle, float meanFreePath) {
+  c->particleKind = kind;
+  c->sticking = sticking;
+  c->sourcePower = (kind == orc::DIFFUSE || kind == orc::DIFFUSE_COSINE) ? 1.f : sourcePower;
+  c->coneAngle = coneAngle;
+  c->meanFreePath = meanFreePath;
+}
+void orc_set_material_sticking(Context *c, const int *ids, const float *vals, int n) {
+  c->materialSticking.clear();
+  for (int i = 0; i < n; ++i)
+    c->materialSticking.emplace_back(ids[i], vals[i]);
+}
+void orc_set_wdist(Context *c, int on) { c->useWdist = on != 0; }
+// SourceGrid (raySourceGrid.hpp): explicit origins; n == 0 restores SourceRandom
+void orc_set_source_grid(Context *c, const float *pts, unsigned n) {
+  c->sourceGrid.clear();
+  for (unsigned i = 0; i < n; ++i)
+    c->sourceGrid.push_back(orc::Vec3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]});
+  c->sourceKind = n ? 1 : 0;
+}
+// createSourceGrid (rayUtil.hpp:564-611) on the prepared bounding box; returns the point count
+unsigned orc_create_source_grid(Context *c, uint64_t numPoints, float gridDelta, float *out, unsigned cap) {
+  orc::prepare(*c);
+  auto g = orc::createSourceGrid(c->D, c->bdBox, (size_t)numPoints, gridDelta, c->ts);
+  for (unsigned i = 0; i < g.size() && i < cap; ++i)
+    for (int k = 0; k < 3; ++k)
+      out[3 * i + k] = g[i][k];
+  return (unsigned)g.size();
+}
+int orc_num_data(Context *c) { return c->numData(); }
+void orc_get_flux_data(Context *c, int idx, float *out) {
+  std::memcpy(out, c->flux.data() + (size_t)idx * c->numPrims, (size_t)c->numPrims * 4);
+}
 void orc_set_num_rays_per_point(Context *c, uint64_t n) {
   c->numRaysPerPoint = n;
   c->numRaysFixed = 0;
@@ -1529,8 +1741,8 @@ void orc_prepare(Context *c) { orc::prepare(*c); }
 void orc_apply(Context *c, int threads) { orc::apply(*c, threads); }
 
 unsigned orc_num_prims(Context *c) { return c->numPrims; }
-void orc_get_flux(Context *c, float *out) {
-  std::memcpy(out, c->flux.data(), c->flux.size() * sizeof(float));
+void orc_get_flux(Context *c, float *out) { // data label 0
+  std::memcpy(out, c->flux.data(), (size_t)c->numPrims * sizeof(float));
 }
 // numRays,totalRaysTraced,nonGeometryHits,geometryHits,particleHits,
 // boundaryHits,reflections,raysTerminated

@@ -65,5 +65,18 @@ int main(int argc, char **argv) {
     }
   }
   std::printf("acosf: %ld inputs, mismatches %ld; sinf mismatches %ld\n", nA, badA, badSf);
-  return (badS || badC || badP || badA || badSf) ? 1 : 0;
+  // expf on every float in [-110, 0] (mean-free-path scatter probability)
+  long badE = 0, nE = 0;
+  {
+    const uint32_t top = vr::vr_asuint(110.0f);
+#pragma omp parallel for reduction(+ : badE, nE) schedule(static)
+    for (long u = 0; u <= (long)top; u += step) {
+      const float x = -vr::vr_asfloat((uint32_t)u);
+      const float a = expf(x), b = vr::glibc_expf(x);
+      badE += std::memcmp(&a, &b, 4) != 0;
+      ++nE;
+    }
+  }
+  std::printf("expf: %ld inputs, mismatches %ld\n", nE, badE);
+  return (badS || badC || badP || badA || badSf || badE) ? 1 : 0;
 }

@@ -294,17 +294,17 @@ def test_ray_range_shards_sum_to_whole():
 
 
 def test_material_sticking_map():
+    """per-material sticking (gpu::Particle::materialSticking, rayParticle.hpp:208-218): the oracle
+    models the map as a particle whose surfaceReflection looks the material up"""
     pts, nrm = vr.io.plane_grid(32, 1.0)
     mats = (np.arange(32 * 32) % 2).astype(np.int32)
-    t = vr.TraceDisk(3)
-    t.setGeometry(pts, nrm, 1.0)
+    t, o = make_pair_disks(pts, nrm, 1.0, 3, [BC.PERIODIC_BOUNDARY] * 3, TD.POS_Z, ("diffuse", 1.0, 1.0),
+                           rays_fixed=100000, seed=3)
     t.setMaterialIds(mats)
-    t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+    o.set_material_ids(mats)
     t.setParticleType(vr.DiffuseParticle(1.0, "flux", materialSticking={1: 0.5}))
-    t.setNumberOfRaysFixed(100000)
-    t.setRngSeed(3)
-    t.apply()
-    i = info_dict(t)
+    o.set_material_sticking({1: 0.5})
+    err, i = compare(t, o)
     # closest disk of material 1 -> the ray survives with weight 0.5 and reflects
     assert 0.3 * 100000 < i["reflections"] < 0.7 * 100000
 
@@ -918,3 +918,134 @@ def test_device_normalization_matches_oracle(geom):
         same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
         assert same.all(), (geom, norm, np.nanmax(np.abs(got - want)))
         assert ((fused.view(np.uint32) == got.view(np.uint32)) | (np.isnan(fused) & np.isnan(got))).all()
+
+
+# ---------------------------------------------------------------------------
+# particle plug-ins of the device registry, data labels, WDIST crediting,
+# mean-free-path scattering, SourceGrid, host-callback sources
+# ---------------------------------------------------------------------------
+def _plugin_pair(geom, particle, okind, sticking, power=1.0, cone=0.0, mfp=-1.0, rays=30, seed=4242, wdist=False):
+    if geom == "mesh":
+        gd, v, tri = trench_mesh()
+        t = vr.TraceTriangle(3)
+        t.setGeometry(v, tri, gd)
+        o = po.Oracle()
+        o.set_triangles(v, tri, gd, 3)
+    else:
+        gd, p, n = {"trench3d": trench3d, "trench2d": trench2d, "sphere": sphere3d}[geom]()
+        D = 2 if geom == "trench2d" else 3
+        t = vr.TraceDisk(D)
+        t.setGeometry(p, n, gd)
+        o = po.Oracle()
+        o.set_disks(p, n, gd, D)
+        if D == 2:
+            t.setSourceDirection(TD.POS_Y)
+            o.set_source_direction(po.POS_Y)
+            t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 2)
+            o.set_boundary_conditions([po.PERIODIC] * 2)
+    t.setParticleType(particle)
+    o.set_particle_ex(okind, sticking, power, cone, mfp)
+    t.setUseWdist(wdist)
+    o.set_wdist(wdist)
+    t.setNumberOfRaysPerPoint(rays)
+    o.set_num_rays_per_point(rays)
+    t.setRngSeed(seed)
+    o.set_rng_seed(seed)
+    o.set_lazy_rng(True)
+    return t, o
+
+
+@pytest.mark.parametrize("geom", ["trench3d", "mesh", "trench2d"])
+@pytest.mark.parametrize("cone", [0.3, 1.2, 0.0, 2.0])
+def test_coned_cosine_particle_matches_oracle(geom, cone):
+    """ReflectionConedCosine (rayReflection.hpp:52-120) in the extended kernel.  The accept-reject loop
+    and the trigonometry run in double on both sides; the device library's sin / cos are not glibc's bit
+    for bit, which after the narrowing to float changes a direction with probability ~1e-8 per sample:
+    counters are compared exactly (a flip would show) and the flux to the north-star tolerance."""
+    t, o = _plugin_pair(geom, vr.ConedCosineParticle(0.2, 3.0, cone, "flux"), po.CONED_COSINE, 0.2, 3.0, cone)
+    err, i = compare(t, o)
+    assert i["reflections"] > 0
+
+
+@pytest.mark.parametrize("geom", ["trench3d", "mesh"])
+def test_two_label_particle_matches_oracle(geom):
+    """a particle with two data labels (AbstractParticle::getLocalDataLabels): both TracingData vectors"""
+    t, o = _plugin_pair(geom, vr.DiffuseCosineParticle(0.3, "flux", "cosFlux"), po.DIFFUSE_COSINE, 0.3)
+    err, i = compare(t, o)
+    assert t.numData() == 2 and o.num_data() == 2
+    ld = t.getLocalData()
+    assert ld.getVectorDataIndex("cosFlux") == 1
+    a, b = ld.getVectorData("cosFlux"), o.flux_data(1)
+    assert l2_rel(a, b) <= 5e-6 and a.sum() > 0
+    assert (ld.getVectorData("flux") >= a - 1e-3).all()      # cos <= 1
+
+
+@pytest.mark.parametrize("geom", ["trench3d", "sphere", "trench2d"])
+def test_wdist_crediting_matches_oracle(geom):
+    """VIENNARAY_USE_WDIST (rayTraceKernel.hpp:258-296): the hit's weight shared by inverse impact distance"""
+    t, o = _plugin_pair(geom, vr.DiffuseParticle(0.4, "flux"), po.DIFFUSE, 0.4, wdist=True)
+    t.apply()
+    o.apply(po.max_threads())
+    gi, oi = info_dict(t), o.info()
+    assert gi == {k: oi[k] for k in INFO_KEYS}
+    f, r = t.getLocalData().getVectorData(0), o.flux()
+    assert l2_rel(f, r) <= 1e-5
+    # the shares of one hit sum to numDisksHit * w / ... : total weight is conserved per hit
+    t2, o2 = _plugin_pair(geom, vr.DiffuseParticle(0.4, "flux"), po.DIFFUSE, 0.4, wdist=False)
+    t2.apply()
+    assert abs(f.sum() / t2.getLocalData().getVectorData(0).sum() - 1) < 1e-3
+
+
+@pytest.mark.parametrize("geom,mfp", [("trench3d", 20.0), ("mesh", 5.0), ("trench2d", 50.0)])
+def test_mean_free_path_scattering_matches_oracle(geom, mfp):
+    """getMeanFreePath() > 0 (rayTraceKernel.hpp:179-203) with quirk Q1 kept; glibc expf reproduced"""
+    part = vr.DiffuseParticle(0.3, "flux")
+    part.meanFreePath = mfp
+    t, o = _plugin_pair(geom, part, po.DIFFUSE, 0.3, mfp=mfp)
+    err, i = compare(t, o)
+    assert i["particleHits"] > 0
+
+
+def test_source_grid_known_answers_and_parity():
+    """tests/createSourceGrid/createSourceGrid.cpp:43-46 on the product path (origins on the extended top
+    face, directions pointing down) + flux parity of a SourceGrid run against the oracle"""
+    gd, p, n = sphere3d()
+    t, o = make_pair_disks(p, n, gd, 3, [BC.REFLECTIVE_BOUNDARY] * 3, TD.POS_Z, ("specular", 0.5, 2.0), rays_pp=40)
+    grid = o.create_source_grid(len(p), gd)
+    # origins lie on the source face of the adjusted bounding box: top of the geometry + 2 x padding
+    # (the reference test pads by gridDelta and asserts 1 + 2 gridDelta; apply() pads by the disk radius)
+    assert len(grid) > 0 and np.allclose(grid[:, 2], o.bbox()[1, 2], atol=1e-6)
+    assert abs(o.bbox()[1, 2] - (1.0 + 2 * o.disk_radius())) < 1e-5
+    t.setSource(vr.SourceGrid(grid))
+    o.set_source_grid(grid)
+    org, d = t.debugSourceSample(np.arange(len(grid), dtype=np.uint64), 1)
+    assert (d[:, 2] < 0).all()
+    assert np.allclose(org, grid, atol=1e-6)
+    err, i = compare(t, o)
+    assert i["numRays"] == len(grid) * 40
+    # resetSource(): back to the random source, bit-identical to a tracer that never had a grid
+    t.resetSource()
+    o.set_source_grid(None)
+    compare(t, o)
+
+
+@pytest.mark.parametrize("sticking", [1.0, 0.2])
+def test_host_callback_rays_reproduce_the_internal_source(sticking):
+    """setSource(custom Source): the rays a host callback produced (here: exactly what SourceRandom would
+    have produced, with the 4 engine outputs it consumes) give the bit-identical run — the per-ray RNG
+    continues where the callback left it"""
+    gd, p, n = trench3d()
+    t = vr.TraceDisk(3)
+    t.setGeometry(p, n, gd)
+    t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+    t.setParticleType(vr.DiffuseParticle(sticking, "flux"))
+    t.setNumberOfRaysFixed(200000)
+    t.setRngSeed(11)
+    t.apply()
+    f0, i0 = t.getFluxF64(), info_dict(t)
+    org, d = t.debugSourceSample(np.arange(200000, dtype=np.uint64), 12)  # kernel seed = rngSeed + runNumber(1)
+    t.setHostRays(org, d, np.full(200000, 4, dtype=np.uint32))
+    t.setRunNumber(1)
+    t.apply()
+    assert info_dict(t) == i0
+    assert (t.getFluxF64() == f0).all()

@@ -35,7 +35,7 @@ class TraceInfoPOD(C.Structure):
 class ParticlePOD(C.Structure):
     _fields_ = [("kind", C.c_int32), ("sticking", C.c_float), ("sourcePower", C.c_float),
                 ("numMaterialSticking", C.c_int32), ("materialIds", C.POINTER(C.c_int32)),
-                ("materialSticking", C.POINTER(C.c_float))]
+                ("materialSticking", C.POINTER(C.c_float)), ("coneAngle", C.c_float), ("meanFreePath", C.c_float)]
 
 
 # every symbol include/viennaray_amd.h declares: name -> (restype, argtypes)
@@ -57,6 +57,9 @@ SIGNATURES = {
     "vr_set_source_direction": (C.c_int, [_vp, C.c_int]),
     "vr_set_primary_direction": (C.c_int, [_vp, _fp]),
     "vr_set_particle": (C.c_int, [_vp, C.POINTER(ParticlePOD)]),
+    "vr_set_use_wdist": (C.c_int, [_vp, C.c_int]),
+    "vr_set_source_grid": (C.c_int, [_vp, _fp, C.c_uint32]),
+    "vr_set_host_rays": (C.c_int, [_vp, _fp, _fp, _u32p, C.c_uint64]),
     "vr_set_number_of_rays_per_point": (C.c_int, [_vp, C.c_uint64]),
     "vr_set_number_of_rays_fixed": (C.c_int, [_vp, C.c_uint64]),
     "vr_set_max_reflections": (C.c_int, [_vp, C.c_uint32]),
@@ -73,6 +76,8 @@ SIGNATURES = {
     "vr_num_primitives": (C.c_uint32, [_vp]),
     "vr_get_flux": (C.c_int, [_vp, _fp, C.c_uint32]),
     "vr_get_flux_f64": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_uint32]),
+    "vr_num_data": (C.c_uint32, [_vp]),
+    "vr_get_flux_data": (C.c_int, [_vp, C.c_uint32, _fp, C.c_uint32]),
     "vr_get_trace_info": (C.c_int, [_vp, C.POINTER(TraceInfoPOD)]),
     "vr_get_trace_mode": (C.c_int, [_vp, _i32p]),
     "vr_normalize_flux": (C.c_int, [_vp, _fp, C.c_uint32, C.c_int]),

@@ -15,6 +15,7 @@
 #include "../../include/viennaray_amd.h"
 #include "vr_host.hpp"
 #include "vr_kernels.hpp"
+#include "vr_particles.hpp"
 #include "vr_types.hpp"
 
 using namespace vr;
@@ -71,6 +72,17 @@ struct vr_context {
   float primaryDirection[3] = {0, 0, 0};
   bool haveParticle = false;
   int particleKind = 0;
+  float coneAngle = 0.f, meanFreePath = -1.f;
+  bool useWdist = false;
+  uint32_t numData = 1;           // data labels of the particle (accumulator planes)
+  uint32_t accPlanes = 0;         // planes the accumulator buffers currently hold
+  // sources other than SourceRandom
+  std::vector<float> gridPoints;  // SourceGrid origins (raySourceGrid.hpp)
+  std::vector<float> hostOrg, hostDir;
+  std::vector<uint32_t> hostDraws;
+  bool sourceDirty = false;
+  DevBuf<float> dGrid, dHostOrg, dHostDir;
+  DevBuf<uint32_t> dHostDraws;
   float sticking = 1.f, sourcePower = 1.f;
   std::vector<int32_t> matStickIds;
   std::vector<float> matStickVals;
@@ -118,6 +130,7 @@ struct vr_context {
   float keyCoord = 0.f;          // sort plane of the ray stream on the tracing axis (host_sort_plane)
   float keyShare = 1.f;          // share of the surface shown to the source that lies in that plane
   int traceMode = 0;             // trace_kernel MODE of the prepared launch
+  int kernelParticle = 0;        // PARTICLE template id of the prepared launch (P_EXT: extended kernel)
   SetupParams lastSetup{};       // buffers of the resident device build (vr_debug_bvh_check)
   bool haveSetup = false;
   int builtOrderAxis = -1;       // child order of the resident BVH (source side first)
@@ -317,12 +330,15 @@ int vr_set_primary_direction(vr_context *c, const float *d) {
   return VR_OK;
 }
 int vr_set_particle(vr_context *c, const vr_particle *p) {
-  if (!c || !p || (p->kind != VR_PARTICLE_DIFFUSE && p->kind != VR_PARTICLE_SPECULAR))
-    return fail(c, VR_E_INVALID, "vr_set_particle: bad argument");
+  if (!c || !p || p->kind < VR_PARTICLE_DIFFUSE || p->kind > VR_PARTICLE_DIFFUSE_COSINE)
+    return fail(c, VR_E_INVALID, "vr_set_particle: unknown particle kind (not in the device registry)");
   c->particleKind = p->kind;
   c->sticking = p->sticking;
   // rayParticle.hpp:158,199
-  c->sourcePower = p->kind == VR_PARTICLE_DIFFUSE ? 1.f : p->sourcePower;
+  c->sourcePower = (p->kind == VR_PARTICLE_DIFFUSE || p->kind == VR_PARTICLE_DIFFUSE_COSINE) ? 1.f : p->sourcePower;
+  c->coneAngle = p->coneAngle;
+  c->meanFreePath = p->meanFreePath;
+  c->numData = (uint32_t)Particles::numData(p->kind);
   c->matStickIds.clear();
   c->matStickVals.clear();
   if (p->numMaterialSticking > 0 && p->materialIds && p->materialSticking) {
@@ -332,6 +348,41 @@ int vr_set_particle(vr_context *c, const vr_particle *p) {
   c->haveParticle = true;
   c->prepared = false;
   c->configDirty = true;
+  return VR_OK;
+}
+int vr_set_use_wdist(vr_context *c, int on) {
+  if (!c)
+    return VR_E_INVALID;
+  c->useWdist = on != 0;
+  c->prepared = false;
+  return VR_OK;
+}
+// Source = SourceGrid(points, particle's cosine power) (raySourceGrid.hpp); n == 0: back to SourceRandom
+int vr_set_source_grid(vr_context *c, const float *points3, uint32_t n) {
+  if (!c || (n && !points3))
+    return fail(c, VR_E_INVALID, "vr_set_source_grid: bad argument");
+  c->gridPoints.assign(points3, points3 + (size_t)n * 3);
+  c->hostOrg.clear();
+  c->hostDir.clear();
+  c->hostDraws.clear();
+  c->sourceDirty = true;
+  c->prepared = false;
+  return VR_OK;
+}
+// Rays of a host-side Source callback for the NEXT applies: ray idx starts at org3[3 idx] towards
+// dir3[3 idx] having consumed draws[idx] outputs of its engine (NULL: none).  n == 0: back to SourceRandom.
+int vr_set_host_rays(vr_context *c, const float *org3, const float *dir3, const uint32_t *draws, uint64_t n) {
+  if (!c || (n && (!org3 || !dir3)) || n > 0xFFFFFFFFull)
+    return fail(c, VR_E_INVALID, "vr_set_host_rays: bad argument");
+  c->hostOrg.assign(org3, org3 + (size_t)n * 3);
+  c->hostDir.assign(dir3, dir3 + (size_t)n * 3);
+  if (draws && n)
+    c->hostDraws.assign(draws, draws + (size_t)n);
+  else
+    c->hostDraws.clear();
+  c->gridPoints.clear();
+  c->sourceDirty = true;
+  c->prepared = false;
   return VR_OK;
 }
 int vr_set_number_of_rays_per_point(vr_context *c, uint64_t n) {
@@ -471,9 +522,8 @@ static int build_scene(vr_context *c) {
       R &= R - 1u;
     c->accReplicas = R;
     c->accStride = (N + 15u) & ~15u; // replicas start on 128-byte lines
-    VR_HIP(c, c->dFluxAcc.ensure((size_t)c->accStride * R));
+    c->accPlanes = 0;                // (buffers are sized per data label in vr_apply_prepare)
   }
-  VR_HIP(c, c->dFluxOrig.ensure(N));
   VR_HIP(c, c->dCounters.ensure(64));
   VR_HIP(c, c->dNbOff.ensure((size_t)N + 1));
   const char *hb = std::getenv("VR_HOST_BUILD");
@@ -801,7 +851,12 @@ int vr_apply_prepare(vr_context *c) {
   const float *dStick = c->havePrimSticking ? c->dPrimSticking.p : nullptr;
   c->configDirty = false;
 
-  const uint64_t numRays = c->numRaysFixed == 0 ? (uint64_t)N * c->numRaysPerPoint : c->numRaysFixed;
+  // rayTraceKernel.hpp:57-61: numRaysFixed, or source.getNumPoints() * numRaysPerPoint
+  // (SourceRandom: the geometry's points; SourceGrid: the grid's; host rays: exactly those given)
+  const uint64_t srcPoints = !c->gridPoints.empty() ? c->gridPoints.size() / 3 : N;
+  uint64_t numRays = c->numRaysFixed == 0 ? srcPoints * c->numRaysPerPoint : c->numRaysFixed;
+  if (!c->hostOrg.empty())
+    numRays = c->hostOrg.size() / 3;
   c->numRaysLast = numRays;
   uint64_t first = 0, last = numRays;
   if (c->rayCount) {
@@ -820,6 +875,37 @@ int vr_apply_prepare(vr_context *c) {
   c->absorb = c->sticking >= 1.f;
   for (float v : c->matStickVals)
     c->absorb = c->absorb && v >= 1.f;
+  // the extended kernel (vr_particles.hpp) serves everything beyond the two built-in particles
+  const bool extended = c->particleKind >= VR_PARTICLE_CONED_COSINE || c->useWdist || c->meanFreePath > 0.f;
+  if (extended)
+    c->absorb = false;
+  c->kernelParticle = extended ? (int)P_EXT : c->particleKind;
+  // accumulators: one plane per data label, each replicated accReplicas times
+  if (c->accPlanes != c->numData) {
+    VR_HIP(c, c->dFluxAcc.ensure((size_t)c->accStride * c->accReplicas * c->numData));
+    VR_HIP(c, c->dFluxOrig.ensure((size_t)N * c->numData));
+    c->accPlanes = c->numData;
+  }
+  if (c->boundFlux && c->boundFluxN != N * c->numData)
+    return fail(c, VR_E_STATE, "bound accumulator buffer does not hold numPrims x numData int64");
+  // source data
+  if (c->sourceDirty) {
+    if (!c->gridPoints.empty()) {
+      VR_HIP(c, c->dGrid.ensure(c->gridPoints.size()));
+      VR_HIP(c, hipMemcpy(c->dGrid.p, c->gridPoints.data(), c->gridPoints.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!c->hostOrg.empty()) {
+      VR_HIP(c, c->dHostOrg.ensure(c->hostOrg.size()));
+      VR_HIP(c, c->dHostDir.ensure(c->hostDir.size()));
+      VR_HIP(c, hipMemcpy(c->dHostOrg.p, c->hostOrg.data(), c->hostOrg.size() * 4, hipMemcpyHostToDevice));
+      VR_HIP(c, hipMemcpy(c->dHostDir.p, c->hostDir.data(), c->hostDir.size() * 4, hipMemcpyHostToDevice));
+      if (!c->hostDraws.empty()) {
+        VR_HIP(c, c->dHostDraws.ensure(c->hostDraws.size()));
+        VR_HIP(c, hipMemcpy(c->dHostDraws.p, c->hostDraws.data(), c->hostDraws.size() * 4, hipMemcpyHostToDevice));
+      }
+    }
+    c->sourceDirty = false;
+  }
 
   // ---- ray stream: one batch of up to 2^27 rays; larger launches run several batches and
   // overlap the generator of batch b+1 (second stream) with the tracer of batch b ----------
@@ -866,7 +952,7 @@ int vr_apply_prepare(vr_context *c) {
     if (const char *e = std::getenv("VR_ABSORB_CARRY"))
       if (c->absorb)
         c->traceMode = std::atoi(e) ? 2 : 1;
-    int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->particleKind, c->traceMode));
+    int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->kernelParticle, c->traceMode));
     if (c->overlap && blocks > 4)
       blocks -= 2; // leave wave slots for the concurrently running generator / sorter
     if (const char *e = std::getenv("VR_TRACE_BLOCKS"))
@@ -879,7 +965,7 @@ int vr_apply_prepare(vr_context *c) {
     size_t waves = 0;
     if (!c->absorb)
       waves = (size_t)c->grid * (VR_BLOCK / 64);
-    if (c->usePrimaryDirection)
+    if (c->usePrimaryDirection || !c->hostOrg.empty())
       waves = std::max(waves, (size_t)c->numCUs * 8u * (VR_BLOCK / 64)); // launch_gen's grid bound
     if (waves > c->scratchWaves) {
       VR_HIP(c, c->dScratch.ensure(waves * 312u * 64u));
@@ -920,6 +1006,18 @@ int vr_apply_prepare(vr_context *c) {
   p.wallTable = c->dWalls.p;
   p.fluxAcc = c->dFluxAcc.p;
   p.accStride = c->accStride;
+  p.numData = c->numData;
+  p.planeStride = c->accStride * c->accReplicas;
+  p.particleKind = c->particleKind;
+  p.coneAngle = c->coneAngle;
+  p.meanFreePath = c->meanFreePath;
+  p.useWdist = c->useWdist ? 1 : 0;
+  p.gridPoints = c->gridPoints.empty() ? nullptr : c->dGrid.p;
+  p.gridCount = (uint32_t)(c->gridPoints.size() / 3);
+  p.eeGrid = 2.f / (c->sourcePower + 1); // raySourceGrid.hpp:22
+  p.hostOrg = c->hostOrg.empty() ? nullptr : c->dHostOrg.p;
+  p.hostDir = c->hostOrg.empty() ? nullptr : c->dHostDir.p;
+  p.hostDraws = c->hostDraws.empty() ? nullptr : c->dHostDraws.p;
   p.accMask = c->accReplicas - 1u;
   p.counters = c->dCounters.p;
   p.workCounter = c->dCounters.p + 8;
@@ -1067,7 +1165,7 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   // a small batch does not need the whole persistent grid: one wave per 64 rays is plenty
   const unsigned gridBatch =
       (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(c->grid, ((uint64_t)count + 255) / 256));
-  VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->particleKind, c->traceMode, gridBatch, c->stream));
+  VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->kernelParticle, c->traceMode, gridBatch, c->stream));
   VR_HIP(c, hipEventRecord(c->evK[2 * batchNo + 1], c->stream));
   if (c->overlap)
     VR_HIP(c, hipEventRecord(c->evTraced[batchNo], c->stream));
@@ -1081,7 +1179,7 @@ int vr_apply_launch(vr_context *c) {
     return fail(c, VR_E_STATE, "vr_apply_launch: call vr_apply_prepare first");
   VR_HIP(c, hipSetDevice(c->device));
   const uint32_t N = c->geo.numPrims;
-  VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)c->accStride * c->accReplicas * 8, c->stream));
+  VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)c->accStride * c->accReplicas * c->numData * 8, c->stream));
   VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64 * 8, c->stream));
   VR_HIP(c, hipEventRecord(c->ev0, c->stream));
   if (c->overlap)
@@ -1096,7 +1194,9 @@ int vr_apply_launch(vr_context *c) {
     ++c->numBatches;
   }
   VR_HIP(c, hipEventRecord(c->ev1, c->stream));
-  VR_HIP(c, launch_gather_flux(c->dFluxAcc.p, c->accStride, c->accReplicas, c->dLeafOfOrig.p, N, c->fluxOut(), c->stream));
+  for (uint32_t l = 0; l < c->numData; ++l)
+    VR_HIP(c, launch_gather_flux(c->dFluxAcc.p + (size_t)l * c->accStride * c->accReplicas, c->accStride, c->accReplicas,
+                                 c->dLeafOfOrig.p, N, c->fluxOut() + (size_t)l * N, c->stream));
   c->launched = true;
   return VR_OK;
 }
@@ -1172,16 +1272,37 @@ int vr_apply(vr_context *c) {
 // ---- results --------------------------------------------------------------------
 uint32_t vr_num_primitives(const vr_context *c) { return c ? c->geo.numPrims : 0; }
 
-int vr_get_flux_f64(vr_context *c, double *out, uint32_t n) {
+uint32_t vr_num_data(const vr_context *c) { return c ? c->numData : 0; }
+
+static int get_flux_plane_f64(vr_context *c, uint32_t dataIdx, double *out, uint32_t n);
+
+int vr_get_flux_f64(vr_context *c, double *out, uint32_t n) { return get_flux_plane_f64(c, 0, out, n); }
+
+// getLocalData().getVectorData(dataIdx): the particle's data label `dataIdx`
+int vr_get_flux_data(vr_context *c, uint32_t dataIdx, float *out, uint32_t n) {
+  if (!c || !out)
+    return VR_E_INVALID;
+  std::vector<double> tmp(n);
+  int r = get_flux_plane_f64(c, dataIdx, tmp.data(), n);
+  if (r != VR_OK)
+    return r;
+  for (uint32_t i = 0; i < n; ++i)
+    out[i] = (float)tmp[i];
+  return VR_OK;
+}
+
+static int get_flux_plane_f64(vr_context *c, uint32_t dataIdx, double *out, uint32_t n) {
   if (!c || !out)
     return VR_E_INVALID;
   if (!c->haveResult)
     return fail(c, VR_E_STATE, "vr_get_flux: no result (call vr_apply)");
   if (n != c->geo.numPrims)
     return fail(c, VR_E_INVALID, "vr_get_flux: size mismatch");
+  if (dataIdx >= c->numData)
+    return fail(c, VR_E_INVALID, "vr_get_flux_data: the particle has no such data label");
   VR_HIP(c, hipSetDevice(c->device));
   std::vector<unsigned long long> acc(n);
-  VR_HIP(c, hipMemcpy(acc.data(), c->fluxOut(), (size_t)n * 8, hipMemcpyDeviceToHost));
+  VR_HIP(c, hipMemcpy(acc.data(), c->fluxOut() + (size_t)dataIdx * n, (size_t)n * 8, hipMemcpyDeviceToHost));
   const double scale = std::ldexp(1.0, -VR_FLUX_FRAC_BITS);
   for (uint32_t i = 0; i < n; ++i)
     out[i] = (double)acc[i] * scale;
@@ -1236,15 +1357,15 @@ int vr_flux_accumulators(vr_context *c, void **devPtr, uint32_t *n) {
     return fail(c, VR_E_STATE, "vr_flux_accumulators: no result");
   *devPtr = c->fluxOut();
   if (n)
-    *n = c->geo.numPrims;
+    *n = c->geo.numPrims * c->numData;
   return VR_OK;
 }
 
 int vr_bind_flux_accumulators(vr_context *c, void *devPtr, uint32_t n) {
   if (!c)
     return VR_E_INVALID;
-  if (devPtr && n != c->geo.numPrims)
-    return fail(c, VR_E_INVALID, "vr_bind_flux_accumulators: size mismatch (set the geometry first)");
+  if (devPtr && n != c->geo.numPrims * c->numData)
+    return fail(c, VR_E_INVALID, "vr_bind_flux_accumulators: size mismatch (numPrims x data labels; set geometry and particle first)");
   c->boundFlux = (unsigned long long *)devPtr;
   c->boundFluxN = devPtr ? n : 0;
   return VR_OK;

@@ -390,19 +390,29 @@ __device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, 
   // together.  Testing a leaf the moment one lane reaches it would run the (long)
   // primitive test with a handful of lanes on almost every step.
   unsigned pend = 0u; // pending leaf link (VR_LEAF bit set) or 0
+  // The loop bodies are PREDICATED, not branched: a lane that is not searching (parked, done, or
+  // never took part) runs the step on node 0 and discards it.  An exec-masked step costs the same
+  // issue slots as a full one, and the mask juggling of a divergent `if` was a third of the
+  // instructions of this loop; two steps run between the wave-level votes for the same reason.
   for (;;) {
     bool parked = false;
     for (;;) {
-      const bool search = node < p.numNodes && !parked;
-      const unsigned long long sm = ballot64(search);
+      const bool search0 = node < p.numNodes && !parked;
+      const unsigned long long sm = ballot64(search0);
       if (!sm)
         break;
       const unsigned long long km = ballot64(parked);
       if (100u * (unsigned)__popcll(km) >= p.walkPark * (unsigned)__popcll(km | sm))
         break;
-      if (search) {
-        DIAG(1);
-        const uint4 nd = qnodes[node];
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const bool search = node < p.numNodes && !parked;
+#ifdef VR_DIAG
+        if (search) {
+          DIAG(1);
+        }
+#endif
+        const uint4 nd = qnodes[search ? node : 0u];
         const float lx = (float)(nd.x & 0xFFFFu), ly = (float)(nd.x >> 16), lz = (float)(nd.y & 0xFFFFu);
         const float hx = (float)(nd.y >> 16), hy = (float)(nd.z & 0xFFFFu), hz = (float)(nd.z >> 16);
         const float tx0 = __builtin_fmaf(lx, inv.x, -oi.x), tx1 = __builtin_fmaf(hx, inv.x, -oi.x);
@@ -413,36 +423,37 @@ __device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, 
         const unsigned link = nd.w;
         const bool leaf = (link & VR_LEAF) != 0u;
         const bool hitBox = tEntry <= tExit && tEntry <= h.t;
-        if (hitBox && leaf) {
-          if (pend == 0u)
-            pend = link;
-          else
-            parked = true; // second leaf: wait here (the node is visited again afterwards)
-        }
+        const bool take = search && hitBox && leaf;
+        const bool park = take && pend != 0u; // second leaf: wait here (the node is visited again afterwards)
+        pend = (take && pend == 0u) ? link : pend;
+        parked = parked || park;
         // pre-order: first child of an internal node / escape of a leaf = next node
-        if (!parked)
-          node = (hitBox || leaf) ? node + 1u : link;
+        const unsigned nxt = (hitBox || leaf) ? node + 1u : link;
+        node = (search && !park) ? nxt : node;
       }
     }
     if (ballot64(pend != 0u)) {
       const unsigned first = pend & VR_LEAF_FIRST_MASK;
       const unsigned cnt = pend ? (pend >> 27) & 15u : 0u;
       for (unsigned i = 0; ballot64(i < cnt); ++i) {
-        if (i < cnt) {
+        const bool on = i < cnt;
+#ifdef VR_DIAG
+        if (on) {
           DIAG(2);
-          const unsigned q = first + i;
-          float t;
-          if (GEO == 0) {
-            const float4 c4 = prims[2 * q];
-            const float4 n4 = prims[2 * q + 1];
-            const bool ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
-            hit_update(h, ok, t, __float_as_uint(n4.w), q);
-          } else {
-            const float4 a = prims[4 * q], b = prims[4 * q + 1], c = prims[4 * q + 2], e = prims[4 * q + 3];
-            const bool ok =
-                hit_tri(o, d, tnear, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(e.x, e.y, e.z), t);
-            hit_update(h, ok, t, __float_as_uint(a.w), q);
-          }
+        }
+#endif
+        const unsigned q = on ? first + i : 0u;
+        float t;
+        if (GEO == 0) {
+          const float4 c4 = prims[2 * q];
+          const float4 n4 = prims[2 * q + 1];
+          const bool ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
+          hit_update(h, on && ok, t, __float_as_uint(n4.w), q);
+        } else {
+          const float4 a = prims[4 * q], b = prims[4 * q + 1], c = prims[4 * q + 2], e = prims[4 * q + 3];
+          const bool ok =
+              hit_tri(o, d, tnear, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(e.x, e.y, e.z), t);
+          hit_update(h, on && ok, t, __float_as_uint(a.w), q);
         }
       }
       pend = 0u;
@@ -738,6 +749,28 @@ __device__ __forceinline__ bool local_disc_hit(const V3 &ro, const V3 &rd, const
   hp.y = hp.y - c.y;
   hp.z = hp.z - c.z;
   const float dist = sqrtf(vdot(hp, hp));
+  return c4.w > dist;
+}
+
+// the same test, also returning the distance between the point of impact and the disc centre
+// (VIENNARAY_USE_WDIST, rayTraceKernel.hpp:258-296); false leaves dist undefined
+__device__ __forceinline__ bool local_disc_hit_dist(const V3 &ro, const V3 &rd, const float4 &c4, const V3 &n,
+                                                    float &dist) {
+  const float prod = vdot(n, rd);
+  if (prod > 0.f)
+    return false;
+  if (fabsf(prod) < 1e-6f)
+    return false;
+  const V3 c = V3{c4.x, c4.y, c4.z};
+  const float ddneg = vdot(c, n);
+  const float tt = (ddneg - vdot(n, ro)) / prod;
+  if (tt <= 0.f)
+    return false;
+  V3 hp = V3{rd.x * tt + ro.x, rd.y * tt + ro.y, rd.z * tt + ro.z};
+  hp.x = hp.x - c.x;
+  hp.y = hp.y - c.y;
+  hp.z = hp.z - c.z;
+  dist = sqrtf(vdot(hp, hp));
   return c4.w > dist;
 }
 

@@ -210,4 +210,37 @@ VR_HD float glibc_acosf(float x) {
   return 2.0f * (df + w);
 }
 
+// glibc 2.35 expf (sysdeps/ieee754/flt-32/e_expf.c, x86-64 fma variant), for x <= 0: the
+// mean-free-path scatter probability 1 - exp(-t / lambda) (rayTraceKernel.hpp:181-182)
+VR_HD float glibc_expf(float x) {
+  static const uint64_t exp2tab[32] = {
+      0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+      0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+      0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+      0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+      0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+      0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+      0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+      0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+  if (!(x >= -0x1.9fe368p6f)) // below: underflow to +0 (NaN arguments do not occur here)
+    return 0.0f;
+  const double N = 32.0;
+  const double InvLn2N = 0x1.71547652b82fep+0 * N, SHIFT = 0x1.8p+52;
+  const double C0 = 0x1.c6af84b912394p-5 / N / N / N, C1 = 0x1.ebfce50fac4f3p-3 / N / N, C2 = 0x1.62e42ff0c52d6p-1 / N;
+  const double xd = (double)x;
+  const double z = InvLn2N * xd;
+  double kd = z + SHIFT;
+  const uint64_t ki = vr_asuint64(kd);
+  kd -= SHIFT;
+  const double r = z - kd;
+  uint64_t t = exp2tab[ki % 32u];
+  t += ki << 47;
+  const double sc = vr_asdouble(t);
+  const double zz = __builtin_fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = __builtin_fma(C2, r, 1.0);
+  y = __builtin_fma(zz, r2, y);
+  return (float)(y * sc);
+}
+
 } // namespace vr

@@ -22,8 +22,11 @@
 //                   (rayTraceKernel.hpp:155-335).
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "vr_device.hpp"
 #include "vr_kernels.hpp"
+#include "vr_particles.hpp"
 
 namespace vr {
 
@@ -179,6 +182,52 @@ template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_basi
   }
 }
 
+// SourceGrid (raySourceGrid.hpp:25-66): origin = grid[idx % numPoints], direction from two draws
+// (cosf / sinf / powf / sqrtf in float, then Normalize)
+template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_grid_kernel(const TraceParams p) {
+  for (unsigned i = blockIdx.x * VR_BLOCK + threadIdx.x; i < p.batchCount; i += gridDim.x * VR_BLOCK) {
+    const unsigned long long idx = p.idxList ? p.idxList[i] : p.batchFirst + i;
+    u64 out[2], lo, hi;
+    mt_first_outputs<2>(tea3((unsigned)idx, p.seed), out, lo, hi);
+    const float r1 = canon_f32(out[0]), r2 = canon_f32(out[1]);
+    const float *g = p.gridPoints + 3 * (size_t)(idx % p.gridCount);
+    const V3 o = mk(g[0], g[1], g[2]);
+    const float tt = glibc_powf(r2, p.eeGrid);
+    const float ang = (float)(3.14159265358979323846 * 2.f * (double)r1);
+    float sn, cs;
+    glibc_sincosf(ang, sn, cs);
+    V3 d = mk(0.f, 0.f, 0.f);
+    setc(d, p.rayDir, p.posNeg * sqrtf(tt));
+    setc(d, p.firstDir, cs * sqrtf(1.f - tt));
+    setc(d, p.secondDir, D == 2 ? 0.f : sn * sqrtf(1.f - tt));
+    vnormalize(d);
+    gen_store<D, KEEP>(p, i, o, d, 2u, lo, hi);
+  }
+}
+
+// Rays produced by a host-side Source callback (raySource.hpp:10-19): origin, direction and the
+// number of engine outputs the callback consumed; the record's RNG cursors continue from there
+template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_host_kernel(const TraceParams p) {
+  const unsigned tid = threadIdx.x;
+  const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
+  u64 *scratchLane = p.rngScratch + (size_t)gwave * (312u * 64u) + (tid & 63u);
+  for (unsigned i = blockIdx.x * VR_BLOCK + tid; i < p.batchCount; i += gridDim.x * VR_BLOCK) {
+    const unsigned long long idx = p.idxList ? p.idxList[i] : p.batchFirst + i;
+    const V3 o = mk(p.hostOrg[3 * idx], p.hostOrg[3 * idx + 1], p.hostOrg[3 * idx + 2]);
+    const V3 d = mk(p.hostDir[3 * idx], p.hostDir[3 * idx + 1], p.hostDir[3 * idx + 2]);
+    Rng rng;
+    rng_init(rng, tea3((unsigned)idx, p.seed), scratchLane);
+    if (KEEP) {
+      unsigned t2 = 0;
+      const unsigned k = p.hostDraws ? p.hostDraws[idx] : 0u;
+      for (unsigned j = 0; j < k && j < 156u; ++j)
+        (void)rng_next(rng, t2);
+      rng.k = k; // (k >= 156: the trace kernel rebuilds the full state from the seed and skips k outputs)
+    }
+    gen_store<D, KEEP>(p, i, o, d, rng.k, rng.lo, rng.hi);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // exclusive scan (in place), 2048 elements per block: radix-sort digit tables, neighbour offsets
 // ---------------------------------------------------------------------------
@@ -236,27 +285,6 @@ __global__ __launch_bounds__(VR_BLOCK) void scan_add_kernel(unsigned *data, unsi
       data[base + k] += off;
 }
 
-// ---------------------------------------------------------------------------
-// reflection sampling (rayUtil.hpp:266-283 + rayReflection.hpp:31-50)
-// ---------------------------------------------------------------------------
-template <int D> __device__ __forceinline__ V3 reflect_diffuse(const V3 &n, Rng &rng, unsigned &t2 VR_DIAG_ARGS) {
-  float x, y;
-  double x2py2;
-  do {
-    DIAG(7);
-    x = canon_f32(rng_next(rng, t2)) * 2.0f + -1.0f;
-    y = canon_f32(rng_next(rng, t2)) * 2.0f + -1.0f;
-    x2py2 = (double)(x * x + y * y);
-  } while (x2py2 >= 1.);
-  const double tmp = 2. * sqrt(1. - x2py2);
-  x = (float)((double)x * tmp);
-  y = (float)((double)y * tmp);
-  const float z = (float)(1. - 2 * x2py2);
-  V3 r = mk(x + n.x, y + n.y, D == 3 ? z + n.z : 0.f);
-  vnormalize(r);
-  return r;
-}
-
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
   unsigned long long s = v;
 #pragma unroll
@@ -305,6 +333,10 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
 __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 8 : (MODE == 2 ? 7 : 6), MODE == 1 ? 8 : (MODE == 2 ? 7 : 6)))) void
 trace_kernel(const TraceParams p) {
   constexpr bool ABSORB = MODE != 0;
+  // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
+  // extended kernel — particle kind, data labels, WDIST crediting and mean-free-path scattering
+  // decided at run time from TraceParams (vr_particles.hpp)
+  constexpr bool EXT = PARTICLE == P_EXT;
   // CARRY: lanes whose BVH walk is still under way when most of the wave is done keep
   // their cursor over the state-machine / refill phase (see the round structure below).
   // The absorbing kernel for flat scenes does without: its rounds are packets, and the extra
@@ -324,7 +356,7 @@ trace_kernel(const TraceParams p) {
     cntS[k * VR_BLOCK + tid] = 0u;
   __syncthreads();
   unsigned *const cnt = cntS + tid; // counter k of this lane: cnt[k * VR_BLOCK]
-  enum { K_TRACES = 0, K_NONGEO, K_GEO, K_BOUNDARY, K_REFL, K_TERM, K_TIER2 };
+  enum { K_TRACES = 0, K_NONGEO, K_GEO, K_BOUNDARY, K_REFL, K_TERM, K_TIER2, K_PARTICLE };
 #define VR_COUNT(k, v) atomicAdd(&cnt[(k) * VR_BLOCK], (unsigned)(v))
 
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
@@ -523,7 +555,23 @@ trace_kernel(const TraceParams p) {
         active = false;
       } else {
         const V3 hitPoint = mk(org.x + dir.x * h.t, org.y + dir.y * h.t, org.z + dir.z * h.t);
-        if (h.geom == 0) { // boundary, :206-214 + rayBoundary.hpp:29-127
+        bool scattered = false;
+        if (EXT && p.meanFreePath > 0.f) {
+          // mean-free-path scatter (rayTraceKernel.hpp:179-203), quirk Q1 kept: tested after the
+          // closest hit was found, and the origin moves by dir * rnd (the uniform number itself)
+          const float rnd = canon_f32(rng_next(rng, cnt[K_TIER2 * VR_BLOCK]));
+          const float scatterProbability = (float)(1. - (double)glibc_expf(-h.t / p.meanFreePath));
+          if (rnd < scatterProbability) {
+            org = mk(org.x + dir.x * rnd, org.y + dir.y * rnd, org.z + dir.z * rnd);
+            rayDirection = pick_random_point_on_unit_sphere(rng, cnt[K_TIER2 * VR_BLOCK]);
+            dir = project_dir<D>(rayDirection);
+            VR_COUNT(K_PARTICLE, 1);
+            scattered = true;
+          }
+        }
+        if (scattered) {
+          // (reflect = true; continue)
+        } else if (h.geom == 0) { // boundary, :206-214 + rayBoundary.hpp:29-127
           if (++boundaryHits > p.maxBoundaryHits) {
             VR_COUNT(K_TERM, 1);
             active = false;
@@ -581,26 +629,69 @@ trace_kernel(const TraceParams p) {
             VR_COUNT(K_GEO, 1);
             DIAG(11);
             const u64 wfx = weight_fx(rayWeight);
-            // surfaceCollision, rayParticle.hpp:148-156
-            if (!(p.debugFlags & 1u)) {
-              if (aggregate)
-                credit_aggregated(fluxAcc, true, h.pos, wfx);
-              else
-                atomicAdd(&fluxAcc[h.pos], wfx);
-            }
-            if (GEO == 0 && !(p.debugFlags & 4u)) {
-              // every overlapping neighbour disk is credited the full weight (:271-300)
-              const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
-              for (unsigned j = nb; j < ne; ++j) {
-                DIAG(6);
-                const unsigned q = p.nbIds[j];
-                const float4 c4 = prims[2 * q];
-                const float4 n4 = prims[2 * q + 1];
-                const bool hitN = local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u);
+            if (!EXT) {
+              // surfaceCollision, rayParticle.hpp:148-156
+              if (!(p.debugFlags & 1u)) {
                 if (aggregate)
-                  credit_aggregated(fluxAcc, hitN, q, wfx);
-                else if (hitN)
-                  atomicAdd(&fluxAcc[q], wfx);
+                  credit_aggregated(fluxAcc, true, h.pos, wfx);
+                else
+                  atomicAdd(&fluxAcc[h.pos], wfx);
+              }
+              if (GEO == 0 && !(p.debugFlags & 4u)) {
+                // every overlapping neighbour disk is credited the full weight (:271-300)
+                const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
+                for (unsigned j = nb; j < ne; ++j) {
+                  DIAG(6);
+                  const unsigned q = p.nbIds[j];
+                  const float4 c4 = prims[2 * q];
+                  const float4 n4 = prims[2 * q + 1];
+                  const bool hitN = local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u);
+                  if (aggregate)
+                    credit_aggregated(fluxAcc, hitN, q, wfx);
+                  else if (hitN)
+                    atomicAdd(&fluxAcc[q], wfx);
+                }
+              }
+            } else {
+              // plug-in particles: Particles::collide decides what each credited primitive's data
+              // labels receive; with WDIST the weight is shared by inverse impact distance
+              // (rayTraceKernel.hpp:258-296: w / d_i / sum(1/d) * numDisksHit, closest disk first)
+              const int kind = p.particleKind;
+              auto creditTo = [&](unsigned q, float w, const V3 &nq) {
+                Particles::collide(kind, w, rayDirection, nq, [&](int label, float v) {
+                  atomicAdd(&fluxAcc[(size_t)label * p.planeStride + q], weight_fx(v));
+                });
+              };
+              if (GEO == 0) {
+                const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
+                float invSum = 0.f, dClosest = 0.f;
+                unsigned numHit = 1;
+                if (p.useWdist) {
+                  const float4 cp = prims[2 * h.pos];
+                  const V3 dv = mk(hitPoint.x - cp.x, hitPoint.y - cp.y, hitPoint.z - cp.z);
+                  dClosest = sqrtf(vdot(dv, dv)) + 1e-6f;
+                  invSum = 0.f + 1.f / dClosest;
+                  for (unsigned j = nb; j < ne; ++j) {
+                    const unsigned q = p.nbIds[j];
+                    const float4 n4 = prims[2 * q + 1];
+                    float dist;
+                    if (local_disc_hit_dist(org, dir, prims[2 * q], mk(n4.x, n4.y, n4.z), dist)) {
+                      invSum += 1.f / (dist + 1e-6f);
+                      ++numHit;
+                    }
+                  }
+                }
+                creditTo(h.pos, p.useWdist ? rayWeight / dClosest / invSum * (float)numHit : rayWeight, geomNormal);
+                for (unsigned j = nb; j < ne; ++j) {
+                  const unsigned q = p.nbIds[j];
+                  const float4 n4 = prims[2 * q + 1];
+                  const V3 nq = mk(n4.x, n4.y, n4.z);
+                  float dist;
+                  if (local_disc_hit_dist(org, dir, prims[2 * q], nq, dist))
+                    creditTo(q, p.useWdist ? rayWeight / (dist + 1e-6f) / invSum * (float)numHit : rayWeight, nq);
+                }
+              } else {
+                creditTo(h.pos, rayWeight, geomNormal);
               }
             }
             if (ABSORB) {
@@ -616,9 +707,11 @@ trace_kernel(const TraceParams p) {
                 // surfaceReflection, rayParticle.hpp:137-146 / 178-187
                 V3 newDir;
                 if (PARTICLE == 0)
-                  newDir = reflect_diffuse<D>(geomNormal, rng, cnt[K_TIER2 * VR_BLOCK] VR_DIAG_PASS);
-                else
+                  newDir = reflection_diffuse<D>(geomNormal, rng, cnt[K_TIER2 * VR_BLOCK]);
+                else if (PARTICLE == 1)
                   newDir = reflect_specular(rayDirection, geomNormal);
+                else
+                  newDir = Particles::reflect<D>(p.particleKind, p, rayDirection, geomNormal, rng, cnt[K_TIER2 * VR_BLOCK]);
                 rayWeight = wAfter;
                 if (++numReflections > p.maxReflections) { // :320-324
                   VR_COUNT(K_TERM, 1);
@@ -667,7 +760,7 @@ trace_kernel(const TraceParams p) {
   }
 #endif
   // (slot order of vr_types.hpp: traces, nongeo, geo, particle, boundary, reflections, terminated, tier2)
-  const unsigned vals[8] = {cnt[K_TRACES * VR_BLOCK], cnt[K_NONGEO * VR_BLOCK], cnt[K_GEO * VR_BLOCK], 0u,
+  const unsigned vals[8] = {cnt[K_TRACES * VR_BLOCK], cnt[K_NONGEO * VR_BLOCK], cnt[K_GEO * VR_BLOCK], cnt[K_PARTICLE * VR_BLOCK],
                             cnt[K_BOUNDARY * VR_BLOCK], cnt[K_REFL * VR_BLOCK], cnt[K_TERM * VR_BLOCK],
                             cnt[K_TIER2 * VR_BLOCK]};
 #undef VR_COUNT
@@ -688,17 +781,21 @@ hipError_t launch_gen(const TraceParams &p, int D, bool keepRng, unsigned maxBlo
     return hipSuccess;
   if (grid > maxBlocks)
     grid = maxBlocks; // grid-stride; bounds the tier-2 slabs to grid waves
-  const int key = (p.useBasis ? 4 : 0) | (D == 2 ? 0 : 2) | (keepRng ? 1 : 0);
+  // source: SourceRandom (0: axis-aligned, 1: tilted primary direction), SourceGrid (2), host rays (3)
+  const int src = p.hostOrg ? 3 : (p.gridPoints ? 2 : (p.useBasis ? 1 : 0));
+  const int key = src * 4 + (D == 2 ? 0 : 2) + (keepRng ? 1 : 0);
+#define VR_GEN(K, DD, KEEP)                                                                                           \
+  case K: hipLaunchKernelGGL((gen_kernel<DD, KEEP>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;                     \
+  case 4 + K: hipLaunchKernelGGL((gen_basis_kernel<DD, KEEP>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;            \
+  case 8 + K: hipLaunchKernelGGL((gen_grid_kernel<DD, KEEP>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;             \
+  case 12 + K: hipLaunchKernelGGL((gen_host_kernel<DD, KEEP>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
   switch (key) {
-  case 0: hipLaunchKernelGGL((gen_kernel<2, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 1: hipLaunchKernelGGL((gen_kernel<2, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 2: hipLaunchKernelGGL((gen_kernel<3, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 3: hipLaunchKernelGGL((gen_kernel<3, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 4: hipLaunchKernelGGL((gen_basis_kernel<2, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 5: hipLaunchKernelGGL((gen_basis_kernel<2, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  case 6: hipLaunchKernelGGL((gen_basis_kernel<3, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
-  default: hipLaunchKernelGGL((gen_basis_kernel<3, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
+    VR_GEN(0, 2, false)
+    VR_GEN(1, 2, true)
+    VR_GEN(2, 3, false)
+    VR_GEN(3, 3, true)
   }
+#undef VR_GEN
   return hipGetLastError();
 }
 
@@ -728,22 +825,32 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
 }
 
 // mode: 0 general, 1 absorbing + flat scene, 2 absorbing + structured scene
+// particle: 0 DiffuseParticle, 1 SpecularParticle, 2 (P_EXT) extended kernel (always mode 0)
+template <class F> static auto dispatch_variant(int D, int geo, int particle, F &&f) {
+  const int key = (D == 2 ? 0 : 6) + (geo ? 3 : 0) + particle;
+  switch (key) {
+  case 0: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  case 1: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  case 2: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+  case 3: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  case 4: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  case 5: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+  case 6: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  case 7: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+  case 8: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+  case 9: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+  case 10: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  default: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+  }
+}
+
 hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int mode, unsigned grid,
                         hipStream_t s) {
-  const bool absorb = mode != 0;
-  if (absorb)
-    particle = 0; // the reflection model is unobservable: one instantiation serves both
-  const int key = (D == 2 ? 0 : 4) | (geo ? 2 : 0) | (particle ? 1 : 0);
-  switch (key) {
-  case 0: return launch_trace_t<2, 0, 0>(p, mode, grid, s);
-  case 1: return launch_trace_t<2, 0, 1>(p, mode, grid, s);
-  case 2: return launch_trace_t<2, 1, 0>(p, mode, grid, s);
-  case 3: return launch_trace_t<2, 1, 1>(p, mode, grid, s);
-  case 4: return launch_trace_t<3, 0, 0>(p, mode, grid, s);
-  case 5: return launch_trace_t<3, 0, 1>(p, mode, grid, s);
-  case 6: return launch_trace_t<3, 1, 0>(p, mode, grid, s);
-  default: return launch_trace_t<3, 1, 1>(p, mode, grid, s);
-  }
+  if (mode != 0)
+    particle = 0; // the reflection model is unobservable: one instantiation serves all
+  return dispatch_variant(D, geo, particle, [&](auto d, auto g, auto pt) {
+    return launch_trace_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(p, mode, grid, s);
+  });
 }
 
 template <int D, int GEO, int PARTICLE> static int occ_t(int mode) {
@@ -761,17 +868,9 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode) {
 int trace_blocks_per_cu(int D, int geo, int particle, int mode) {
   if (mode != 0)
     particle = 0;
-  const int key = (D == 2 ? 0 : 4) | (geo ? 2 : 0) | (particle ? 1 : 0);
-  switch (key) {
-  case 0: return occ_t<2, 0, 0>(mode);
-  case 1: return occ_t<2, 0, 1>(mode);
-  case 2: return occ_t<2, 1, 0>(mode);
-  case 3: return occ_t<2, 1, 1>(mode);
-  case 4: return occ_t<3, 0, 0>(mode);
-  case 5: return occ_t<3, 0, 1>(mode);
-  case 6: return occ_t<3, 1, 0>(mode);
-  default: return occ_t<3, 1, 1>(mode);
-  }
+  return dispatch_variant(D, geo, particle, [&](auto d, auto g, auto pt) {
+    return occ_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(mode);
+  });
 }
 
 // ---- diagnostics -----------------------------------------------------------

@@ -56,8 +56,20 @@ struct TraceParams {
   const uint32_t *nbIds;      // leaf positions
   const float *primSticking;  // optional [numPrims] (leaf order) or nullptr
   const float *wallTable;     // 8 x {v0, e1, e2, Ng} = 96 floats
-  unsigned long long *fluxAcc;   // [numPrims] leaf order, fixed point 2^-40
+  unsigned long long *fluxAcc;   // [numData][replicas][accStride] leaf order, fixed point 2^-40
   uint32_t accStride, accMask;   // replica r of the accumulators starts at fluxAcc + r * accStride; r = blockIdx & accMask
+  uint32_t numData, planeStride; // data label l (TracingData vector l) lives at fluxAcc + l * planeStride
+  // particle plug-ins (vr_particles.hpp): run-time kind of the extended kernel instantiation
+  int32_t particleKind;
+  float coneAngle, meanFreePath;
+  int32_t useWdist;              // VIENNARAY_USE_WDIST crediting (rayTraceKernel.hpp:258-296)
+  // sources other than SourceRandom: SourceGrid origins (raySourceGrid.hpp), or rays a host-side
+  // Source callback produced (origin, direction, engine outputs it consumed)
+  const float *gridPoints;
+  uint32_t gridCount;
+  float eeGrid;
+  const float *hostOrg, *hostDir;
+  const uint32_t *hostDraws;
   unsigned long long *counters;  // [8]
   unsigned long long *workCounter;
   unsigned long long *rngScratch; // [waves][312][64]
@@ -128,6 +140,9 @@ struct SetupParams {
   uint32_t *nbOff, *nbIds;
   float *wide;            // 64-ary box tree (see TraceParams::wide), (n + n/64 + ...) x 8 floats
 };
+
+// particle kinds of the device registry (include/viennaray_amd.h: VR_PARTICLE_*)
+enum { P_DIFFUSE = 0, P_SPECULAR = 1, P_CONED_COSINE = 2, P_DIFFUSE_COSINE = 3, P_EXT = 2 /* template id of the extended kernel */ };
 
 // counters[] slots
 enum {

@@ -42,7 +42,7 @@ class GpuShard:
         """(Re-)bind the accumulator tensor.  setGeometry() drops an external binding (the
         primitive count may have changed), so this runs before every launch."""
         import torch
-        n = self.tr._n
+        n = self.tr._n * max(1, self.tr.numData())
         if self.acc is None or self.acc.numel() != n:
             self.acc = torch.zeros(n, dtype=torch.int64, device=self.device)
         self.tr.bindFluxAccumulators(self.acc.data_ptr(), n)

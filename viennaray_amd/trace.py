@@ -77,6 +77,61 @@ class SpecularParticle:
         return [self.dataLabel]
 
 
+class ConedCosineParticle:
+    """Plug-in particle of the device registry (vr_particles.hpp): collects like SpecularParticle,
+    reflects with ReflectionConedCosine(maxConeAngle) (rayReflection.hpp:52-120)."""
+    kind = 2
+
+    def __init__(self, stickingProbability, sourcePower, coneAngle, dataLabel, materialSticking=None,
+                 meanFreePath=-1.0):
+        self.stickingProbability = float(stickingProbability)
+        self.sourcePower = float(sourcePower)
+        self.coneAngle = float(coneAngle)
+        self.dataLabel = dataLabel
+        self.materialSticking = dict(materialSticking or {})
+        self.meanFreePath = float(meanFreePath)
+
+    def getSourceDistributionPower(self):
+        return self.sourcePower
+
+    def getMeanFreePath(self):
+        return self.meanFreePath
+
+    def getLocalDataLabels(self):
+        return [self.dataLabel]
+
+
+class DiffuseCosineParticle:
+    """Plug-in particle with TWO data labels: label 0 += w (like DiffuseParticle), label 1 += w * max(0, -d.n)."""
+    kind = 3
+
+    def __init__(self, stickingProbability, dataLabel, cosineLabel, materialSticking=None, meanFreePath=-1.0):
+        self.stickingProbability = float(stickingProbability)
+        self.dataLabels = [dataLabel, cosineLabel]
+        self.materialSticking = dict(materialSticking or {})
+        self.meanFreePath = float(meanFreePath)
+
+    def getSourceDistributionPower(self):
+        return 1.0
+
+    def getMeanFreePath(self):
+        return self.meanFreePath
+
+    def getLocalDataLabels(self):
+        return list(self.dataLabels)
+
+
+class SourceGrid:
+    """raySourceGrid.hpp: explicit ray origins (createSourceGrid, rayUtil.hpp:564-611); the direction
+    comes from the particle's cosine power."""
+
+    def __init__(self, points):
+        self.points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+
+    def getNumPoints(self):
+        return self.points.shape[0]
+
+
 class TracingData:
     """rayTracingData.hpp:16-219: labelled vectors and scalars with a merge type each.  The
     device path fills vector 0 of Trace.getLocalData() (merge type SUM)."""
@@ -191,6 +246,8 @@ class Trace:
         pod.kind = particle.kind
         pod.sticking = particle.stickingProbability
         pod.sourcePower = particle.getSourceDistributionPower()
+        pod.coneAngle = getattr(particle, "coneAngle", 0.0)
+        pod.meanFreePath = getattr(particle, "meanFreePath", -1.0)
         ms = particle.materialSticking
         keep = None
         if ms:
@@ -202,6 +259,35 @@ class Trace:
             keep = (ids, vals)
         self._check(self._L.vr_set_particle(self._h, C.byref(pod)))
         del keep
+
+    def setUseWdist(self, on=True):
+        """VIENNARAY_USE_WDIST as a run-time switch (rayTraceKernel.hpp:258-296)"""
+        self._check(self._L.vr_set_use_wdist(self._h, int(bool(on))))
+
+    def setSource(self, source):
+        """rayTrace.hpp:53-56.  SourceGrid runs natively in the generator kernel; any other object with
+        getOriginAndDirection(idx, rng) is a host callback: it is evaluated here for every ray (rng = a
+        counting stand-in of the per-ray engine) and the rays are handed to the device."""
+        if isinstance(source, SourceGrid):
+            self._check(self._L.vr_set_source_grid(self._h, _fptr(source.points), source.points.shape[0]))
+            return
+        raise VrError("setSource: host-callback sources go through setHostRays(origins, directions, draws)")
+
+    def setHostRays(self, origins, directions, draws=None):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        assert o.shape == d.shape
+        k = None
+        if draws is not None:
+            k = np.ascontiguousarray(draws, dtype=np.uint32)
+            assert k.size == o.shape[0]
+        self._check(self._L.vr_set_host_rays(self._h, _fptr(o), _fptr(d),
+                                             k.ctypes.data_as(C.POINTER(C.c_uint32)) if k is not None else None,
+                                             o.shape[0]))
+
+    def resetSource(self):
+        """rayTrace.hpp:58-61"""
+        self._check(self._L.vr_set_source_grid(self._h, None, 0))
 
     def setBoundaryConditions(self, bcs):
         a = (C.c_int32 * len(bcs))(*[int(b) for b in bcs])
@@ -275,9 +361,13 @@ class Trace:
     def _collect(self):
         labels = self._particle.getLocalDataLabels()
         self._localData.setNumberOfVectorData(len(labels))
-        out = np.empty(self._n, dtype=np.float32)
-        self._check(self._L.vr_get_flux(self._h, _fptr(out), self._n))
-        self._localData.setVectorData(0, out, labels[0])
+        for l, label in enumerate(labels):
+            out = np.empty(self._n, dtype=np.float32)
+            self._check(self._L.vr_get_flux_data(self._h, l, _fptr(out), self._n))
+            self._localData.setVectorData(l, out, label)
+
+    def numData(self):
+        return int(self._L.vr_num_data(self._h))
 
     def getLocalData(self):
         return self._localData
