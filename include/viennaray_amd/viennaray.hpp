@@ -16,9 +16,17 @@
 // double is accepted and converted at the boundary, as the reference does when
 // it fills Embree's float buffers (rayGeometryDisk.hpp:137-175).
 //
-// Not covered (out of scope): user-defined AbstractParticle /
-// Source subclasses — per-hit host callbacks cannot run inside a HIP kernel.
-// setParticleType() accepts the two built-in particles only.
+// Particles and sources.  AbstractParticle / Particle<Derived> / Source carry the reference's
+// virtual interfaces (rayParticle.hpp:21-122, raySource.hpp:10-19), so user classes compile
+// unchanged.  What runs on the device is decided by AbstractParticle::deviceModel(): the
+// built-in particles (and the plug-ins of viennaray_amd/csrc/vr_particles.hpp) describe
+// themselves as a vr_particle POD; a user particle whose per-hit logic exists only as host
+// virtuals cannot be called from a HIP kernel — apply() reports that instead of tracing
+// something else, and the way in is a model in the device registry plus a deviceModel()
+// override.  Sources: SourceGrid runs natively in the generator kernel; any other Source is
+// evaluated on the host once per ray (getOriginAndDirection with a counting stand-in of the
+// per-ray engine) and the rays are handed to the device, which continues each ray's random
+// stream where the callback left it.
 #pragma once
 
 #include <algorithm>
@@ -30,6 +38,7 @@
 #include <iostream>
 #include <limits>
 #include <memory>
+#include <random>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -97,6 +106,38 @@ VectorType<T, D> ScaleAdd(const VectorType<T, D> &a, const VectorType<T, D> &b, 
   return f * a + b;
 }
 template <class T> Vec3D<T> ComputeNormal(const Vec3D<Vec3D<T>> &p) { return CrossProduct(p[1] - p[0], p[2] - p[0]); }
+
+// vcRNG.hpp: viennacore::RNG is std::mt19937_64.  Here a thin wrapper with the same
+// UniformRandomBitGenerator interface that also counts the outputs drawn: a host-side Source
+// callback consumes part of a ray's random stream and the device continues after it.
+struct RNG {
+  using result_type = std::mt19937_64::result_type;
+  std::mt19937_64 engine;
+  uint64_t draws = 0;
+  RNG() = default;
+  explicit RNG(result_type seed) : engine(seed) {}
+  void seed(result_type s) {
+    engine.seed(s);
+    draws = 0;
+  }
+  static constexpr result_type min() { return std::mt19937_64::min(); }
+  static constexpr result_type max() { return std::mt19937_64::max(); }
+  result_type operator()() {
+    ++draws;
+    return engine();
+  }
+};
+
+// vcRNG.hpp tea<N>: the per-ray seed hash (rayTraceKernel.hpp:120)
+template <unsigned N> inline unsigned tea(unsigned v0, unsigned v1) {
+  unsigned s0 = 0;
+  for (unsigned n = 0; n < N; ++n) {
+    s0 += 0x9e3779b9u;
+    v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+    v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+  }
+  return v0;
+}
 
 struct Timer {
   std::chrono::steady_clock::time_point t0;
@@ -302,59 +343,391 @@ template <class NumericType> struct DataLog {
   }
 };
 
-// raySource.hpp:10-19.  A user-defined source is a host callback per ray and cannot run in
-// the generator kernel: Trace::setSource() records the request and
-// apply() then reports an error instead of silently tracing something else.
+} // namespace viennaray
+
+namespace rayInternal {
+using namespace viennacore;
+// rayUtil.hpp:266-283
+template <typename NumericType> viennacore::Vec3D<NumericType> pickRandomPointOnUnitSphere(viennacore::RNG &rngState) {
+  static thread_local std::uniform_real_distribution<NumericType> uniDist(NumericType(-1), NumericType(1));
+  NumericType x, y, z;
+  double x2py2;
+  do {
+    x = uniDist(rngState);
+    y = uniDist(rngState);
+    x2py2 = x * x + y * y;
+  } while (x2py2 >= 1.);
+  double tmp = 2. * std::sqrt(1. - x2py2);
+  x *= tmp;
+  y *= tmp;
+  z = 1. - 2 * x2py2;
+  return viennacore::Vec3D<NumericType>{x, y, z};
+}
+// rayUtil.hpp:145-202: {rayDir, firstDir, secondDir, minMax, posNeg}
+inline std::array<int, 5> getTraceSettings(unsigned sourceDir) {
+  switch (sourceDir) {
+  case 0: return {0, 1, 2, 1, -1}; // POS_X
+  case 1: return {0, 1, 2, 0, 1};  // NEG_X
+  case 2: return {1, 0, 2, 1, -1}; // POS_Y
+  case 3: return {1, 0, 2, 0, 1};  // NEG_Y
+  case 4: return {2, 0, 1, 1, -1}; // POS_Z
+  default: return {2, 0, 1, 0, 1}; // NEG_Z
+  }
+}
+template <int D> constexpr double DiskFactor = 0.5 * (D == 3 ? 1.7320508 : 1.41421356237) * (1 + 1e-5); // rayUtil.hpp:99-101
+
+// rayUtil.hpp:104-143 (direction: viennaray::TraceDirection, passed as its underlying value 0..5)
+template <typename NumericType, int D, class Direction>
+void adjustBoundingBox(std::array<viennacore::Vec3D<NumericType>, 2> &bdBox, Direction const direction,
+                       NumericType discRadius) {
+  if constexpr (D == 2) {
+    bdBox[0][2] -= discRadius;
+    bdBox[1][2] += discRadius;
+  }
+  switch ((unsigned)direction) {
+  case 0: bdBox[1][0] += 2 * discRadius; break;
+  case 1: bdBox[0][0] -= 2 * discRadius; break;
+  case 2: bdBox[1][1] += 2 * discRadius; break;
+  case 3: bdBox[0][1] -= 2 * discRadius; break;
+  case 4: bdBox[1][2] += 2 * discRadius; break;
+  default: bdBox[0][2] -= 2 * discRadius; break;
+  }
+}
+template <class Direction> std::array<int, 5> getTraceSettings(Direction d) { return getTraceSettings((unsigned)d); }
+
+// rayUtil.hpp:564-611
+template <typename NumericType, int D>
+[[nodiscard]] std::vector<viennacore::Vec3D<NumericType>>
+createSourceGrid(const std::array<viennacore::Vec3D<NumericType>, 2> &pBdBox, const size_t pNumPoints,
+                 const NumericType pGridDelta, const std::array<int, 5> &pTraceSettings) {
+  std::vector<viennacore::Vec3D<NumericType>> sourceGrid;
+  sourceGrid.reserve(pNumPoints);
+  constexpr double eps = 1e-4;
+  auto rayDir = pTraceSettings[0];
+  auto firstDir = pTraceSettings[1];
+  auto secondDir = pTraceSettings[2];
+  auto minMax = pTraceSettings[3];
+  auto len1 = pBdBox[1][firstDir] - pBdBox[0][firstDir];
+  auto len2 = pBdBox[1][secondDir] - pBdBox[0][secondDir];
+  auto numPointsInFirstDir = static_cast<size_t>(round(len1 / pGridDelta));
+  auto numPointsInSecondDir = static_cast<size_t>(round(len2 / pGridDelta));
+  const unsigned long ratio = numPointsInFirstDir / numPointsInSecondDir;
+  numPointsInFirstDir = static_cast<size_t>(std::sqrt(pNumPoints * ratio));
+  numPointsInSecondDir = static_cast<size_t>(std::sqrt(pNumPoints / ratio));
+  auto firstGridDelta = (len1 - 2 * eps) / static_cast<NumericType>(numPointsInFirstDir - 1);
+  auto secondGridDelta = (len2 - 2 * eps) / static_cast<NumericType>(numPointsInSecondDir - 1);
+  viennacore::Vec3D<NumericType> point;
+  point[rayDir] = pBdBox[minMax][rayDir];
+  for (auto uu = pBdBox[0][secondDir] + eps; uu <= pBdBox[1][secondDir] - eps; uu += secondGridDelta) {
+    if constexpr (D == 2)
+      point[secondDir] = 0.;
+    else
+      point[secondDir] = uu;
+    for (auto vv = pBdBox[0][firstDir] + eps; vv <= pBdBox[1][firstDir] - eps; vv += firstGridDelta) {
+      point[firstDir] = vv;
+      sourceGrid.push_back(point);
+    }
+  }
+  sourceGrid.shrink_to_fit();
+  return sourceGrid;
+}
+} // namespace rayInternal
+
+namespace viennaray {
+using namespace viennacore;
+
+// rayReflection.hpp:13-120 — the host-side reflection functions user particles call
+template <typename NumericType, int D = 3>
+[[nodiscard]] Vec3D<NumericType> ReflectionSpecular(const Vec3D<NumericType> &rayDir, const Vec3D<NumericType> &geomNormal) {
+  auto dirOldInv = Inv(rayDir);
+  return NumericType(2 * DotProduct(geomNormal, dirOldInv)) * geomNormal - dirOldInv;
+}
+template <typename NumericType, int D>
+[[nodiscard]] Vec3D<NumericType> ReflectionDiffuse(const Vec3D<NumericType> &geomNormal, RNG &rngState) {
+  auto randomDirection = rayInternal::pickRandomPointOnUnitSphere<NumericType>(rngState);
+  randomDirection[0] += geomNormal[0];
+  randomDirection[1] += geomNormal[1];
+  if constexpr (D == 3)
+    randomDirection[2] += geomNormal[2];
+  else
+    randomDirection[2] = 0;
+  Normalize(randomDirection);
+  return randomDirection;
+}
+template <typename NumericType, int D>
+[[nodiscard]] Vec3D<NumericType> ReflectionConedCosine(const Vec3D<NumericType> &rayDir, const Vec3D<NumericType> &geomNormal,
+                                                       RNG &rng, const NumericType maxConeAngle) {
+  std::uniform_real_distribution<double> rand01(0.0, 1.0);
+  if (maxConeAngle <= NumericType(0))
+    return ReflectionSpecular<NumericType>(rayDir, geomNormal);
+  if (maxConeAngle >= M_PI_2)
+    return ReflectionDiffuse<NumericType, D>(geomNormal, rng);
+  const auto v = Inv(rayDir);
+  Vec3D<NumericType> w = NumericType(NumericType(2) * DotProduct(geomNormal, v)) * geomNormal - v;
+  Normalize(w);
+  Vec3D<NumericType> t, b;
+  if (w[2] < NumericType(-0.999999)) {
+    t = {NumericType(0), NumericType(-1), NumericType(0)};
+    b = {NumericType(-1), NumericType(0), NumericType(0)};
+  } else {
+    const NumericType a = NumericType(1) / (NumericType(1) + w[2]);
+    const NumericType bx = -w[0] * w[1] * a, by = NumericType(1) - w[1] * w[1] * a;
+    t = {NumericType(1) - w[0] * w[0] * a, bx, -w[0]};
+    b = {bx, by, -w[1]};
+  }
+  double theta;
+  for (;;) {
+    const double u = std::sqrt(rand01(rng));
+    const double s = std::sqrt(std::max(1.0 - u, 0.0));
+    theta = maxConeAngle * s;
+    const double rhs = std::cos(M_PI_2 * s) * std::sin(theta);
+    if (rand01(rng) * theta * u <= rhs)
+      break;
+  }
+  const NumericType sinT = std::sin(theta);
+  const NumericType cosT = std::cos(theta);
+  const double phi = 2.0 * M_PI * rand01(rng);
+  NumericType sinP = std::sin(phi), cosP = std::cos(phi);
+  Vec3D<NumericType> dir{sinT * (cosP * t[0] + sinP * b[0]) + cosT * w[0], sinT * (cosP * t[1] + sinP * b[1]) + cosT * w[1],
+                         sinT * (cosP * t[2] + sinP * b[2]) + cosT * w[2]};
+  const NumericType dp = DotProduct(dir, geomNormal);
+  if (dp <= NumericType(0))
+    dir = dir - NumericType(NumericType(2) * dp) * geomNormal;
+  if constexpr (D == 2)
+    dir[2] = NumericType(0);
+  Normalize(dir);
+  return dir;
+}
+
+// raySource.hpp:10-19
 template <typename NumericType> class Source {
 public:
   virtual ~Source() = default;
+  virtual std::array<Vec3D<NumericType>, 2> getOriginAndDirection(size_t idx, RNG &rngState) const = 0;
   [[nodiscard]] virtual size_t getNumPoints() const = 0;
   virtual NumericType getSourceArea() const = 0;
   virtual NumericType getInitialRayWeight(const size_t) const { return 1.; }
 };
 
+// raySourceGrid.hpp:10-74.  Runs natively in the generator kernel (vr_set_source_grid).
+template <typename NumericType, int D> class SourceGrid : public Source<NumericType> {
+  using boundingBoxType = std::array<Vec3D<NumericType>, 2>;
+
+public:
+  SourceGrid(const boundingBoxType &boundingBox, std::vector<Vec3D<NumericType>> &sourceGrid, NumericType cosinePower,
+             const std::array<int, 5> &traceSettings)
+      : bdBox_(boundingBox), sourceGrid_(sourceGrid), numPoints_(sourceGrid.size()), rayDir_(traceSettings[0]),
+        firstDir_(traceSettings[1]), secondDir_(traceSettings[2]), minMax_(traceSettings[3]), posNeg_(traceSettings[4]),
+        ee_(static_cast<NumericType>(2) / (cosinePower + 1)) {}
+
+  std::array<Vec3D<NumericType>, 2> getOriginAndDirection(const size_t idx, RNG &rngState) const override {
+    auto origin = sourceGrid_[idx % numPoints_];
+    Vec3D<NumericType> direction{0., 0., 0.};
+    std::uniform_real_distribution<NumericType> uniDist;
+    auto r1 = uniDist(rngState);
+    auto r2 = uniDist(rngState);
+    NumericType tt = pow(r2, ee_);
+    direction[rayDir_] = posNeg_ * sqrtf(tt);
+    direction[firstDir_] = cosf(M_PI * 2.f * r1) * sqrtf(1.f - tt);
+    if constexpr (D == 2)
+      direction[secondDir_] = 0;
+    else
+      direction[secondDir_] = sinf(M_PI * 2.f * r1) * sqrtf(1.f - tt);
+    Normalize(direction);
+    return {origin, direction};
+  }
+  [[nodiscard]] size_t getNumPoints() const override { return numPoints_; }
+  NumericType getSourceArea() const override {
+    if constexpr (D == 2)
+      return bdBox_[1][firstDir_] - bdBox_[0][firstDir_];
+    else
+      return (bdBox_[1][firstDir_] - bdBox_[0][firstDir_]) * (bdBox_[1][secondDir_] - bdBox_[0][secondDir_]);
+  }
+  [[nodiscard]] const std::vector<Vec3D<NumericType>> &getGrid() const { return sourceGrid_; }
+
+private:
+  const boundingBoxType bdBox_;
+  const std::vector<Vec3D<NumericType>> &sourceGrid_;
+  const size_t numPoints_;
+  const int rayDir_, firstDir_, secondDir_, minMax_;
+  const NumericType posNeg_;
+  const NumericType ee_;
+};
+
+#define VIENNARAY_PARTICLE_STOP                                                                                         \
+  std::pair<NumericType, Vec3D<NumericType>> { NumericType(1), Vec3D<NumericType>{} }
+
+// rayParticle.hpp:21-81
 template <typename NumericType> class AbstractParticle {
 public:
   virtual ~AbstractParticle() = default;
   virtual std::unique_ptr<AbstractParticle> clone() const = 0;
+  virtual void initNew(RNG &rngState) = 0;
+  virtual Vec3D<NumericType> initNewWithDirection(RNG &rngState) = 0;
+  virtual std::pair<NumericType, Vec3D<NumericType>>
+  surfaceReflection(NumericType rayWeight, const Vec3D<NumericType> &rayDir, const Vec3D<NumericType> &geomNormal,
+                    const unsigned int primId, const int materialId, const TracingData<NumericType> *globalData,
+                    RNG &rngState) = 0;
+  virtual void surfaceCollision(NumericType rayWeight, const Vec3D<NumericType> &rayDir,
+                                const Vec3D<NumericType> &geomNormal, const unsigned int primID, const int materialId,
+                                TracingData<NumericType> &localData, const TracingData<NumericType> *globalData,
+                                RNG &rngState) = 0;
   virtual NumericType getSourceDistributionPower() const = 0;
+  virtual NumericType getMeanFreePath() const = 0;
   [[nodiscard]] virtual std::vector<std::string> getLocalDataLabels() const = 0;
-  // what the device needs to know (built-in particles only)
-  virtual void describe(vr_particle &pod) const = 0;
+  virtual void logData(DataLog<NumericType> &log) = 0;
+
+  /// NOT in the reference: how this particle runs on the device.  Fill `pod` with a model of the
+  /// device registry (viennaray_amd/csrc/vr_particles.hpp) and return true.  The default (false)
+  /// means the particle exists only as host virtuals, which a HIP kernel cannot call.
+  virtual bool deviceModel(vr_particle &pod) const {
+    (void)pod;
+    return false;
+  }
 };
 
-template <typename NumericType, int D> class DiffuseParticle : public AbstractParticle<NumericType> {
-  NumericType stickingProbability_;
-  std::string dataLabel_;
+// rayParticle.hpp:83-122: CRTP base implementing clone() and the no-op defaults
+template <typename Derived, typename NumericType> class Particle : public AbstractParticle<NumericType> {
+public:
+  std::unique_ptr<AbstractParticle<NumericType>> clone() const final {
+    return std::make_unique<Derived>(static_cast<Derived const &>(*this));
+  }
+  void initNew(RNG &) override {}
+  Vec3D<NumericType> initNewWithDirection(RNG &) override { return Vec3D<NumericType>{0, 0, 0}; }
+  std::pair<NumericType, Vec3D<NumericType>> surfaceReflection(NumericType, const Vec3D<NumericType> &,
+                                                               const Vec3D<NumericType> &, const unsigned int, const int,
+                                                               const TracingData<NumericType> *, RNG &) override {
+    return VIENNARAY_PARTICLE_STOP;
+  }
+  void surfaceCollision(NumericType, const Vec3D<NumericType> &, const Vec3D<NumericType> &, const unsigned int, const int,
+                        TracingData<NumericType> &, const TracingData<NumericType> *, RNG &) override {}
+  NumericType getSourceDistributionPower() const override { return 1.; }
+  NumericType getMeanFreePath() const override { return -1.; }
+  [[nodiscard]] std::vector<std::string> getLocalDataLabels() const override { return {}; }
+  void logData(DataLog<NumericType> &) override {}
+
+protected:
+  Particle() = default;
+  Particle(const Particle &) = default;
+  Particle(Particle &&) = default;
+};
+
+// rayParticle.hpp:126-163
+template <typename NumericType, int D>
+class DiffuseParticle : public Particle<DiffuseParticle<NumericType, D>, NumericType> {
+  const NumericType stickingProbability_;
+  const std::string dataLabel_;
 
 public:
   DiffuseParticle(NumericType stickingProbability, std::string dataLabel)
       : stickingProbability_(stickingProbability), dataLabel_(std::move(dataLabel)) {}
-  std::unique_ptr<AbstractParticle<NumericType>> clone() const final {
-    return std::make_unique<DiffuseParticle>(*this);
+  std::pair<NumericType, Vec3D<NumericType>> surfaceReflection(NumericType, const Vec3D<NumericType> &,
+                                                               const Vec3D<NumericType> &geomNormal, const unsigned int,
+                                                               const int, const TracingData<NumericType> *,
+                                                               RNG &rngState) final {
+    return {stickingProbability_, ReflectionDiffuse<NumericType, D>(geomNormal, rngState)};
+  }
+  void surfaceCollision(NumericType rayWeight, const Vec3D<NumericType> &, const Vec3D<NumericType> &,
+                        const unsigned int primID, const int, TracingData<NumericType> &localData,
+                        const TracingData<NumericType> *, RNG &) final {
+    localData.getVectorData(0)[primID] += rayWeight;
   }
   NumericType getSourceDistributionPower() const final { return 1.; }
   [[nodiscard]] std::vector<std::string> getLocalDataLabels() const final { return {dataLabel_}; }
-  void describe(vr_particle &pod) const final {
-    pod = vr_particle{VR_PARTICLE_DIFFUSE, (float)stickingProbability_, 1.f, 0, nullptr, nullptr};
+  bool deviceModel(vr_particle &pod) const final {
+    pod = vr_particle{VR_PARTICLE_DIFFUSE, (float)stickingProbability_, 1.f, 0, nullptr, nullptr, 0.f, -1.f};
+    return true;
   }
 };
 
-template <typename NumericType, int D> class SpecularParticle : public AbstractParticle<NumericType> {
-  NumericType stickingProbability_;
-  NumericType sourcePower_;
-  std::string dataLabel_;
+// rayParticle.hpp:165-204
+template <typename NumericType, int D>
+class SpecularParticle : public Particle<SpecularParticle<NumericType, D>, NumericType> {
+  const NumericType stickingProbability_;
+  const NumericType sourcePower_;
+  const std::string dataLabel_;
 
 public:
   SpecularParticle(NumericType stickingProbability, NumericType sourcePower, std::string dataLabel)
       : stickingProbability_(stickingProbability), sourcePower_(sourcePower), dataLabel_(std::move(dataLabel)) {}
-  std::unique_ptr<AbstractParticle<NumericType>> clone() const final {
-    return std::make_unique<SpecularParticle>(*this);
+  std::pair<NumericType, Vec3D<NumericType>> surfaceReflection(NumericType, const Vec3D<NumericType> &rayDir,
+                                                               const Vec3D<NumericType> &geomNormal, const unsigned int,
+                                                               const int, const TracingData<NumericType> *, RNG &) final {
+    return {stickingProbability_, ReflectionSpecular<NumericType, D>(rayDir, geomNormal)};
+  }
+  void surfaceCollision(NumericType rayWeight, const Vec3D<NumericType> &, const Vec3D<NumericType> &,
+                        const unsigned int primID, const int, TracingData<NumericType> &localData,
+                        const TracingData<NumericType> *, RNG &) final {
+    localData.getVectorData(0)[primID] += rayWeight;
   }
   NumericType getSourceDistributionPower() const final { return sourcePower_; }
   [[nodiscard]] std::vector<std::string> getLocalDataLabels() const final { return {dataLabel_}; }
-  void describe(vr_particle &pod) const final {
-    pod = vr_particle{VR_PARTICLE_SPECULAR, (float)stickingProbability_, (float)sourcePower_, 0, nullptr, nullptr};
+  bool deviceModel(vr_particle &pod) const final {
+    pod = vr_particle{VR_PARTICLE_SPECULAR, (float)stickingProbability_, (float)sourcePower_, 0, nullptr, nullptr, 0.f, -1.f};
+    return true;
+  }
+};
+
+// ---- plug-in particles of the device registry (NOT in the reference's rayParticle.hpp; written
+//      against AbstractParticle the way a ViennaPS model is, with a device model each) ------------
+// sticking + ReflectionConedCosine(maxConeAngle), optional mean free path; collects like SpecularParticle
+template <typename NumericType, int D>
+class ConedCosineParticle : public Particle<ConedCosineParticle<NumericType, D>, NumericType> {
+  const NumericType stickingProbability_, sourcePower_, coneAngle_, meanFreePath_;
+  const std::string dataLabel_;
+
+public:
+  ConedCosineParticle(NumericType stickingProbability, NumericType sourcePower, NumericType maxConeAngle,
+                      std::string dataLabel, NumericType meanFreePath = NumericType(-1))
+      : stickingProbability_(stickingProbability), sourcePower_(sourcePower), coneAngle_(maxConeAngle),
+        meanFreePath_(meanFreePath), dataLabel_(std::move(dataLabel)) {}
+  std::pair<NumericType, Vec3D<NumericType>> surfaceReflection(NumericType, const Vec3D<NumericType> &rayDir,
+                                                               const Vec3D<NumericType> &geomNormal, const unsigned int,
+                                                               const int, const TracingData<NumericType> *,
+                                                               RNG &rngState) final {
+    return {stickingProbability_, ReflectionConedCosine<NumericType, D>(rayDir, geomNormal, rngState, coneAngle_)};
+  }
+  void surfaceCollision(NumericType rayWeight, const Vec3D<NumericType> &, const Vec3D<NumericType> &,
+                        const unsigned int primID, const int, TracingData<NumericType> &localData,
+                        const TracingData<NumericType> *, RNG &) final {
+    localData.getVectorData(0)[primID] += rayWeight;
+  }
+  NumericType getSourceDistributionPower() const final { return sourcePower_; }
+  NumericType getMeanFreePath() const final { return meanFreePath_; }
+  [[nodiscard]] std::vector<std::string> getLocalDataLabels() const final { return {dataLabel_}; }
+  bool deviceModel(vr_particle &pod) const final {
+    pod = vr_particle{VR_PARTICLE_CONED_COSINE, (float)stickingProbability_, (float)sourcePower_, 0, nullptr, nullptr,
+                      (float)coneAngle_, (float)meanFreePath_};
+    return true;
+  }
+};
+
+// a DiffuseParticle with two data labels: label 0 += w, label 1 += w * max(0, -d.n)
+template <typename NumericType, int D>
+class DiffuseCosineParticle : public Particle<DiffuseCosineParticle<NumericType, D>, NumericType> {
+  const NumericType stickingProbability_;
+  const std::string dataLabel_, cosineLabel_;
+
+public:
+  DiffuseCosineParticle(NumericType stickingProbability, std::string dataLabel, std::string cosineLabel)
+      : stickingProbability_(stickingProbability), dataLabel_(std::move(dataLabel)), cosineLabel_(std::move(cosineLabel)) {}
+  std::pair<NumericType, Vec3D<NumericType>> surfaceReflection(NumericType, const Vec3D<NumericType> &,
+                                                               const Vec3D<NumericType> &geomNormal, const unsigned int,
+                                                               const int, const TracingData<NumericType> *,
+                                                               RNG &rngState) final {
+    return {stickingProbability_, ReflectionDiffuse<NumericType, D>(geomNormal, rngState)};
+  }
+  void surfaceCollision(NumericType rayWeight, const Vec3D<NumericType> &rayDir, const Vec3D<NumericType> &geomNormal,
+                        const unsigned int primID, const int, TracingData<NumericType> &localData,
+                        const TracingData<NumericType> *, RNG &) final {
+    localData.getVectorData(0)[primID] += rayWeight;
+    localData.getVectorData(1)[primID] += rayWeight * std::max(-DotProduct(rayDir, geomNormal), NumericType(0));
+  }
+  NumericType getSourceDistributionPower() const final { return 1.; }
+  [[nodiscard]] std::vector<std::string> getLocalDataLabels() const final { return {dataLabel_, cosineLabel_}; }
+  bool deviceModel(vr_particle &pod) const final {
+    pod = vr_particle{VR_PARTICLE_DIFFUSE_COSINE, (float)stickingProbability_, 1.f, 0, nullptr, nullptr, 0.f, -1.f};
+    return true;
   }
 };
 
@@ -376,17 +749,25 @@ public:
 
   /// Run the ray tracer
   virtual void apply() {
-    if (pSource_) {
-      RTInfo_.error = true;
-      std::cerr << "viennaray_amd: user-defined sources are not supported on the device path "
-                   "(call resetSource() to use the built-in power-cosine source).\n";
-      return;
-    }
     if (!ctx_ || pParticle_ == nullptr) {
       RTInfo_.error = true;
       std::cerr << "No particle was specified in rayTrace. Aborting.\n";
       return;
     }
+    if (!particleOnDevice_) {
+      RTInfo_.error = true;
+      std::cerr << "viennaray_amd: this particle type has no device model (AbstractParticle::deviceModel): its "
+                   "surfaceCollision / surfaceReflection exist only as host virtuals, which a HIP kernel cannot call. "
+                   "Add a model to viennaray_amd/csrc/vr_particles.hpp and override deviceModel().\n";
+      return;
+    }
+    if (setterError_) { // a setter was refused (e.g. too many primitives): do not trace something else
+      RTInfo_.error = true;
+      std::cerr << vr_last_error(ctx_) << "\n";
+      return;
+    }
+    if (pSource_ && !sourceOnDevice_ && !uploadHostSource())
+      return;
     const int rc = vr_apply(ctx_);
     vr_trace_info i{};
     vr_get_trace_info(ctx_, &i);
@@ -404,20 +785,22 @@ public:
       std::cerr << vr_last_error(ctx_) << "\n";
       return;
     }
-    // rayTraceDisk.hpp:40-47: one zero-initialised vector per data label, then the flux
+    // rayTraceDisk.hpp:40-47: one vector per data label of the particle
     auto labels = pParticle_->getLocalDataLabels();
     localData_.setNumberOfVectorData((int)labels.size());
     const uint32_t n = vr_num_primitives(ctx_);
-    for (int k = 0; k < (int)labels.size(); ++k)
+    const uint32_t nd = vr_num_data(ctx_);
+    for (int k = 0; k < (int)labels.size(); ++k) {
       localData_.setVectorData(k, n, NumericType(0), labels[k]);
-    if (!labels.empty()) {
+      if ((uint32_t)k >= nd)
+        continue;
       if constexpr (std::is_same_v<NumericType, float>) {
-        vr_get_flux(ctx_, localData_.getVectorData(0).data(), n);
+        vr_get_flux_data(ctx_, (uint32_t)k, localData_.getVectorData(k).data(), n);
       } else {
-        std::vector<double> tmp(n);
-        vr_get_flux_f64(ctx_, tmp.data(), n);
+        std::vector<float> tmp(n);
+        vr_get_flux_data(ctx_, (uint32_t)k, tmp.data(), n);
         for (uint32_t j = 0; j < n; ++j)
-          localData_.getVectorData(0)[j] = (NumericType)tmp[j];
+          localData_.getVectorData(k)[j] = (NumericType)tmp[j];
       }
     }
   }
@@ -427,9 +810,9 @@ public:
   void setParticleType(std::unique_ptr<ParticleType> const &particle) {
     pParticle_ = particle->clone();
     vr_particle pod{};
-    pParticle_->describe(pod);
-    if (ctx_)
-      vr_set_particle(ctx_, &pod);
+    particleOnDevice_ = pParticle_->deviceModel(pod);
+    if (ctx_ && particleOnDevice_)
+      check(vr_set_particle(ctx_, &pod));
   }
 
   void setBoundaryConditions(BoundaryCondition boundaryConditions[D]) {
@@ -437,44 +820,72 @@ public:
     for (int i = 0; i < D; ++i)
       b[i] = (int32_t)boundaryConditions[i];
     if (ctx_)
-      vr_set_boundary_conditions(ctx_, b, D);
+      check(vr_set_boundary_conditions(ctx_, b, D));
   }
   void setNumberOfRaysPerPoint(const size_t n) {
+    numRaysPerPoint_ = n;
+    numRaysFixed_ = 0;
     if (ctx_)
-      vr_set_number_of_rays_per_point(ctx_, n);
+      check(vr_set_number_of_rays_per_point(ctx_, n));
   }
   void setNumberOfRaysFixed(const size_t n) {
+    numRaysFixed_ = n;
+    numRaysPerPoint_ = 0;
     if (ctx_)
-      vr_set_number_of_rays_fixed(ctx_, n);
+      check(vr_set_number_of_rays_fixed(ctx_, n));
   }
   void setMaxReflections(const unsigned n) {
     if (ctx_)
-      vr_set_max_reflections(ctx_, n);
+      check(vr_set_max_reflections(ctx_, n));
   }
   void setMaxBoundaryHits(const unsigned n) {
     if (ctx_)
-      vr_set_max_boundary_hits(ctx_, n);
+      check(vr_set_max_boundary_hits(ctx_, n));
   }
   void setSourceDirection(const TraceDirection direction) {
     if (ctx_)
-      vr_set_source_direction(ctx_, (int)direction);
+      check(vr_set_source_direction(ctx_, (int)direction));
   }
   void setPrimaryDirection(const Vec3D<NumericType> primaryDirection) {
     const float d[3] = {(float)primaryDirection[0], (float)primaryDirection[1], (float)primaryDirection[2]};
     if (ctx_)
-      vr_set_primary_direction(ctx_, d);
+      check(vr_set_primary_direction(ctx_, d));
   }
   void setUseRandomSeeds(const bool useRand) {
+    useRandomSeeds_ = useRand;
     if (ctx_)
-      vr_set_use_random_seeds(ctx_, useRand ? 1 : 0);
+      check(vr_set_use_random_seeds(ctx_, useRand ? 1 : 0));
   }
   void setRngSeed(const unsigned int seed) {
+    rngSeed_ = seed;
+    useRandomSeeds_ = false;
     if (ctx_)
-      vr_set_rng_seed(ctx_, seed);
+      check(vr_set_rng_seed(ctx_, seed));
   }
-  // rayTrace.hpp:58-67
-  void setSource(std::shared_ptr<Source<NumericType>> source) { pSource_ = std::move(source); }
-  void resetSource() { pSource_.reset(); }
+  /// VIENNARAY_USE_WDIST (a compile-time option of the reference, CMakeLists.txt:15) as a run-time switch
+  void setUseWdist(const bool on) {
+    if (ctx_)
+      check(vr_set_use_wdist(ctx_, on ? 1 : 0));
+  }
+  // rayTrace.hpp:53-61.  SourceGrid goes to the generator kernel; any other Source is evaluated on the
+  // host at apply() (uploadHostSource)
+  void setSource(std::shared_ptr<Source<NumericType>> source) {
+    pSource_ = std::move(source);
+    sourceOnDevice_ = false;
+    if (!ctx_ || !pSource_)
+      return;
+    if (auto *g = dynamic_cast<SourceGrid<NumericType, D> *>(pSource_.get())) {
+      auto pts = flatten3(g->getGrid());
+      check(vr_set_source_grid(ctx_, pts.data(), (uint32_t)g->getGrid().size()));
+      sourceOnDevice_ = true;
+    }
+  }
+  void resetSource() {
+    pSource_.reset();
+    sourceOnDevice_ = false;
+    if (ctx_)
+      check(vr_set_source_grid(ctx_, nullptr, 0)); // also drops host rays
+  }
   void enableProgressBar() {}
   void disableProgressBar() {}
 
@@ -496,6 +907,62 @@ public:
   [[nodiscard]] vr_context *getContext() { return ctx_; }
 
 protected:
+  void check(int rc) {
+    if (rc != VR_OK) {
+      setterError_ = true;
+      RTInfo_.error = true;
+      std::cerr << "viennaray_amd: " << vr_last_error(ctx_) << "\n";
+    }
+  }
+  void geometryAccepted(int rc) { // a new geometry clears an earlier refusal
+    setterError_ = false;
+    check(rc);
+  }
+  // A user Source is a host callback (raySource.hpp:10-19): evaluate it for every ray of the coming
+  // apply() exactly as the reference's loop would (rayTraceKernel.hpp:118-140: engine seeded with
+  // tea<3>(idx, seed), particle.initNew, source.getOriginAndDirection) and hand the rays over together
+  // with the number of engine outputs each consumed.  Needs a fixed seed (setRngSeed).
+  bool uploadHostSource() {
+    if (useRandomSeeds_) {
+      RTInfo_.error = true;
+      std::cerr << "viennaray_amd: a host-callback Source needs a fixed seed (setRngSeed): the rays are "
+                   "generated on the host before the launch.\n";
+      return false;
+    }
+    uint32_t runNumber = 1;
+    vr_get_run_number(ctx_, &runNumber);
+    const unsigned seed = runNumber + rngSeed_; // rayTraceKernel.hpp:100
+    const size_t perPoint = numRaysPerPoint_, fixed = numRaysFixed_;
+    const size_t numRays = fixed ? fixed : pSource_->getNumPoints() * perPoint;
+    if (numRays == 0 || numRays > 0xFFFFFFFFull) {
+      RTInfo_.error = true;
+      std::cerr << "viennaray_amd: host-callback Source: number of rays must be in [1, 2^32).\n";
+      return false;
+    }
+    std::vector<float> org(numRays * 3), dir(numRays * 3);
+    std::vector<uint32_t> draws(numRays);
+    auto particle = pParticle_->clone();
+    for (size_t idx = 0; idx < numRays; ++idx) {
+      RNG rng(tea<3>((unsigned)idx, seed));
+      particle->initNew(rng);
+      auto pd = particle->initNewWithDirection(rng);
+      auto od = pSource_->getOriginAndDirection(idx, rng);
+      if (pd[0] != NumericType(0) || pd[1] != NumericType(0) || pd[2] != NumericType(0))
+        od[1] = pd; // rayTraceKernel.hpp:138-140
+      for (int k = 0; k < 3; ++k) {
+        org[3 * idx + k] = (float)od[0][k];
+        dir[3 * idx + k] = (float)od[1][k];
+      }
+      draws[idx] = (uint32_t)rng.draws;
+    }
+    const int rc = vr_set_host_rays(ctx_, org.data(), dir.data(), draws.data(), numRays);
+    if (rc != VR_OK) {
+      RTInfo_.error = true;
+      std::cerr << vr_last_error(ctx_) << "\n";
+      return false;
+    }
+    return true;
+  }
   template <class F> void inPlace(std::vector<NumericType> &flux, F f) {
     if (!ctx_)
       return;
@@ -524,6 +991,10 @@ protected:
   DataLog<NumericType> dataLog_;
   std::shared_ptr<Source<NumericType>> pSource_;
   TraceInfo RTInfo_;
+  bool particleOnDevice_ = false, sourceOnDevice_ = false, setterError_ = false;
+  bool useRandomSeeds_ = true;
+  unsigned rngSeed_ = 0;
+  size_t numRaysPerPoint_ = 1000, numRaysFixed_ = 0;
 };
 
 template <class NumericType, int D> class TraceDisk final : public Trace<NumericType, D> {
@@ -540,17 +1011,18 @@ public:
     static_assert(!(D == 3 && Dim == 2), "Setting 2D geometry in 3D trace object");
     auto p = this->flatten3(points), n = this->flatten3(normals);
     if (this->ctx_)
-      vr_set_disks(this->ctx_, p.data(), n.data(), (uint32_t)points.size(), (float)gridDelta, (float)diskRadii, D);
+      this->geometryAccepted(vr_set_disks(this->ctx_, p.data(), n.data(), (uint32_t)points.size(), (float)gridDelta,
+                                          (float)diskRadii, D));
   }
   void setGeometry(const DiskMesh &mesh) {
     auto p = this->flatten3(mesh.nodes), n = this->flatten3(mesh.normals);
     if (this->ctx_)
-      vr_set_disks(this->ctx_, p.data(), n.data(), (uint32_t)mesh.nodes.size(), mesh.gridDelta, 0.f, D);
+      this->geometryAccepted(vr_set_disks(this->ctx_, p.data(), n.data(), (uint32_t)mesh.nodes.size(), mesh.gridDelta, 0.f, D));
   }
   template <typename T> void setMaterialIds(std::vector<T> const &materialIds) {
     std::vector<int32_t> ids(materialIds.begin(), materialIds.end());
     if (this->ctx_)
-      vr_set_material_ids(this->ctx_, ids.data(), (uint32_t)ids.size());
+      this->check(vr_set_material_ids(this->ctx_, ids.data(), (uint32_t)ids.size()));
   }
 };
 
@@ -564,8 +1036,8 @@ public:
       for (int k = 0; k < 3; ++k)
         t[3 * i + k] = triangles[i][k];
     if (this->ctx_)
-      vr_set_triangles(this->ctx_, p.data(), (uint32_t)points.size(), t.data(), (uint32_t)triangles.size(),
-                       (float)gridDelta, D);
+      this->geometryAccepted(vr_set_triangles(this->ctx_, p.data(), (uint32_t)points.size(), t.data(),
+                                              (uint32_t)triangles.size(), (float)gridDelta, D));
   }
   void setGeometry(const TriangleMesh &mesh) {
     std::vector<VectorType<NumericType, 3>> pts(mesh.nodes.size());
@@ -581,7 +1053,7 @@ public:
   template <typename T> void setMaterialIds(std::vector<T> const &materialIds) {
     std::vector<int32_t> ids(materialIds.begin(), materialIds.end());
     if (this->ctx_)
-      vr_set_material_ids(this->ctx_, ids.data(), (uint32_t)ids.size());
+      this->check(vr_set_material_ids(this->ctx_, ids.data(), (uint32_t)ids.size()));
   }
 };
 

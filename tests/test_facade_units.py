@@ -68,3 +68,20 @@ def test_cpp_facade_units(tmp_path):
                            "-o", str(exe)])
     out = subprocess.run([str(exe), os.path.join(DATA, "lineMesh.dat")], capture_output=True, text=True)
     assert out.returncode == 0 and "facade units ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_cpp_facade_interface_builds():
+    """tests/traceInterface/traceInterface.cpp (custom Source subclass, full AbstractParticle / Source virtual
+    signatures, SourceGrid helper chain, plug-in particles) compiles and links against the façade"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), os.path.join(ROOT, "tests", "aux", "facade_interface")],
+                          stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(ROOT, "tests", "aux", "facade_interface"))
+
+
+@pytest.mark.gpu
+def test_cpp_facade_interface_runs():
+    exe = os.path.join(ROOT, "tests", "aux", "facade_interface")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "facade interface ok" in out.stdout, out.stdout + out.stderr
+    assert "numRays 4410" in out.stdout                      # traceInterface.cpp:67
+    assert "no device model" in out.stderr                    # the host-only particle was refused, not replaced
