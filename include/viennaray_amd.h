@@ -197,6 +197,11 @@ void *vr_stream(vr_context *ctx);
 int vr_debug_intersect(vr_context *ctx, const float *org, const float *dir,
                        const float *tnear, uint32_t nrays, int32_t *geomID,
                        uint32_t *primID, float *t);
+/* Boundary::processHit (rayBoundary.hpp:29-127) for hand-built hits, as the reference's
+ * tests/boundaryHit and tests/boundaryHit2D feed it: ray (org, dir) meets wall triangle primID
+ * (0..7) at tfar                                                                              */
+int vr_debug_process_hit(vr_context *ctx, const float *org, const float *dir, const float *tfar,
+                         const uint32_t *primID, uint32_t n, float *outOrg, float *outDir, int32_t *outReflect);
 /* first (origin, direction) of global ray indices idx[] for kernel seed `seed`
  * (raySourceRandom.hpp:25-36 after rayTraceKernel.hpp:120-121)               */
 int vr_debug_source_sample(vr_context *ctx, const uint64_t *idx, uint32_t n,

@@ -52,6 +52,7 @@ def lib():
         L.orc_set_material_sticking.argtypes = [vp, C.POINTER(C.c_int), fp, C.c_int]
         L.orc_set_wdist.argtypes = [vp, C.c_int]
         L.orc_set_source_grid.argtypes = [vp, fp, C.c_uint]
+        L.orc_set_host_rays.argtypes = [vp, fp, fp, C.c_uint]
         L.orc_create_source_grid.argtypes = [vp, C.c_uint64, C.c_float, fp, C.c_uint]
         L.orc_create_source_grid.restype = C.c_uint
         L.orc_num_data.argtypes = [vp]
@@ -213,6 +214,10 @@ class Oracle:
         else:
             a = _f32(pts).reshape(-1, 3)
             self.L.orc_set_source_grid(self.h, _fp(a), a.shape[0])
+
+    def set_host_rays(self, org, dirn):
+        o, d = _f32(org).reshape(-1, 3), _f32(dirn).reshape(-1, 3)
+        self.L.orc_set_host_rays(self.h, _fp(o), _fp(d), o.shape[0])
 
     def create_source_grid(self, num_points, grid_delta):
         out = np.empty((int(num_points) * 2 + 64, 3), dtype=np.float32)

@@ -737,6 +737,8 @@ struct Context {
   // alternative source (raySourceGrid.hpp): 0 = SourceRandom, 1 = SourceGrid
   int sourceKind = 0;
   std::vector<Vec3> sourceGrid;
+  // sourceKind 2: explicit rays (what a user Source callback returned for idx), no draws consumed
+  std::vector<Vec3> hostOrg, hostDir;
   // KernelConfig (rayUtil.hpp:83-94)
   uint64_t numRaysPerPoint = 1000, numRaysFixed = 0;
   unsigned maxReflections = std::numeric_limits<unsigned>::max();
@@ -1283,7 +1285,10 @@ static void traceRay(Context &c, long long idx, unsigned seed, float *flux,
   {
     // initNew: no draws; initNewWithDirection: returns 0 (rayParticle.hpp:91-94)
     Vec3 o, d;
-    if (c.sourceKind == 1)
+    if (c.sourceKind == 2) {
+      o = c.hostOrg[(size_t)idx];
+      d = c.hostDir[(size_t)idx];
+    } else if (c.sourceKind == 1)
       sourceGridSample(c, idx, rngState, o, d);
     else
       sourceSample(c, rngState, o, d);
@@ -1513,9 +1518,9 @@ static void apply(Context &c, int numThreads) {
     c.info.warning = 1;
   // rayTraceKernel.hpp:57-61: numRaysFixed, or source.getNumPoints() * numRaysPerPoint
   const long long srcPoints = c.sourceKind == 1 ? (long long)c.sourceGrid.size() : (long long)c.numPrims;
-  const long long numRays =
-      c.numRaysFixed == 0 ? srcPoints * (long long)c.numRaysPerPoint
-                          : (long long)c.numRaysFixed;
+  const long long numRays = c.sourceKind == 2 ? (long long)c.hostOrg.size()
+                            : c.numRaysFixed == 0 ? srcPoints * (long long)c.numRaysPerPoint
+                                                  : (long long)c.numRaysFixed;
   c.numRaysLast = numRays;
   long long first = 0, last = numRays;
   if (c.rayCount) {
@@ -1700,6 +1705,15 @@ void orc_set_source_grid(Context *c, const float *pts, unsigned n) {
   for (unsigned i = 0; i < n; ++i)
     c->sourceGrid.push_back(orc::Vec3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]});
   c->sourceKind = n ? 1 : 0;
+}
+void orc_set_host_rays(Context *c, const float *org, const float *dir, unsigned n) {
+  c->hostOrg.clear();
+  c->hostDir.clear();
+  for (unsigned i = 0; i < n; ++i) {
+    c->hostOrg.push_back(orc::Vec3{org[3 * i], org[3 * i + 1], org[3 * i + 2]});
+    c->hostDir.push_back(orc::Vec3{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]});
+  }
+  c->sourceKind = n ? 2 : 0;
 }
 // createSourceGrid (rayUtil.hpp:564-611) on the prepared bounding box; returns the point count
 unsigned orc_create_source_grid(Context *c, uint64_t numPoints, float gridDelta, float *out, unsigned cap) {

@@ -1049,3 +1049,169 @@ def test_host_callback_rays_reproduce_the_internal_source(sticking):
     t.apply()
     assert info_dict(t) == i0
     assert (t.getFluxF64() == f0).all()
+
+
+# ---------------------------------------------------------------------------
+# the reference's hand-placed boundary rays (gpu/tests/boundaries/boundaries.cpp:77-78,105-106,133-134 with
+# the rays of gpu/tests/boundaries/TestPipelineTriangle.cu:85-128) traced by the product's full state machine
+# ---------------------------------------------------------------------------
+def _norm(v):
+    v = np.asarray(v, dtype=np.float32)
+    return v / np.float32(np.linalg.norm(v.astype(np.float64)))
+
+
+def _boundary_fixture_3d():
+    nodes = np.array([[1, 0, 0], [0, 0, 0], [1, .5, 0], [0, .5, 0], [1, .5, 1], [0, .5, 1], [1, 1, 1], [0, 1, 1]], np.float32)
+    tris = np.array([[0, 1, 2], [1, 3, 2], [2, 4, 3], [3, 4, 5], [5, 4, 6], [5, 6, 7]], np.uint32)
+    org = np.array([[.5, .5, 1.1], [.5, .5, 1.5]], np.float32)
+    d = np.stack([_norm([0, -1, -.5]), _norm([0, .6, -.5])])
+    return nodes, tris, org, d
+
+
+def test_reference_boundary_rays_3d_reflective():
+    """boundaries.cpp:77-78: ray 0 reaches triangle 3 (the step's side wall) and ray 1 triangle 5 (the top)
+    after one reflection off the y walls each"""
+    nodes, tris, org, d = _boundary_fixture_3d()
+    t = vr.TraceTriangle(3)
+    t.setGeometry(nodes, tris, 0.5)
+    t.setBoundaryConditions([BC.REFLECTIVE_BOUNDARY] * 3)
+    t.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+    t.setRngSeed(1)
+    t.setHostRays(org, d)
+    t.apply()
+    f = t.getLocalData().getVectorData(0)
+    i = info_dict(t)
+    assert f[3] > 0 and f[5] > 0 and f.sum() == 2            # boundaries.cpp:77-78
+    assert i["numRays"] == 2 and i["boundaryHits"] == 2 and i["geometryHits"] == 2 and i["totalRaysTraced"] == 4
+    o = po.Oracle()
+    o.set_triangles(nodes, tris, 0.5, 3)
+    o.set_boundary_conditions([po.REFLECTIVE] * 3)
+    o.set_particle(po.DIFFUSE, 1.0)
+    o.set_rng_seed(1)
+    o.set_host_rays(org, d)
+    o.apply(1)
+    assert (o.flux() == f).all() and {k: o.info()[k] for k in INFO_KEYS} == i
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_reference_boundary_rays_2d(periodic):
+    """boundaries.cpp:105-106 (reflective: triangles 3 and 5) and :133-134 (periodic: 3 and 7), D = 2.
+    The reference's OptiX test pipeline credits every triangle hit; the CPU path this library follows kills
+    a ray that meets a triangle from behind (rayTraceKernel.hpp:242-249), so the expectation is asserted
+    for the rays that arrive from the front and the whole event sequence is compared with the oracle."""
+    nodes = np.array([[0, 0, 0], [.5, 0, 0], [.5, 1, 0], [1, 1, 0]], np.float32)
+    lines = np.array([[0, 1], [1, 2], [2, 3]], np.uint32)
+    v, tri, keep = vr.io.lines_to_triangles(nodes, lines, 0.5)
+    nv = len(v)
+    v = np.concatenate([v, np.array([[.6, 0, -.25], [.6, 0, .25], [.6, 1, .25], [.6, 1, -.25]], np.float32)])
+    tri = np.concatenate([tri, np.array([[nv, nv + 1, nv + 2], [nv, nv + 3, nv + 2]], np.uint32)])
+    org = np.array([[.5, 1.1, 0], [.5, 1.5, 0]], np.float32)
+    d = np.stack([_norm([-1, -.5, 0]), _norm([.6, -.5, 0])])
+    bc = BC.PERIODIC_BOUNDARY if periodic else BC.REFLECTIVE_BOUNDARY
+    t = vr.TraceTriangle(2)
+    t.setGeometry(v, tri, 0.5)
+    t.setSourceDirection(TD.POS_Y)
+    t.setBoundaryConditions([bc] * 2)
+    t.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+    t.setRngSeed(1)
+    t.setHostRays(org, d)
+    t.apply()
+    f = t.getLocalData().getVectorData(0)
+    i = info_dict(t)
+    o = po.Oracle()
+    o.set_triangles(v, tri, 0.5, 2)
+    o.set_source_direction(po.POS_Y)
+    o.set_boundary_conditions([int(bc)] * 2)
+    o.set_particle(po.DIFFUSE, 1.0)
+    o.set_rng_seed(1)
+    o.set_host_rays(org, d)
+    o.set_event_capacity(64)
+    o.apply(1)
+    assert (o.flux() == f).all() and {k: o.info()[k] for k in INFO_KEYS} == i
+    assert i["boundaryHits"] == 2                             # each ray meets one x wall first
+    ev = o.events()
+    reached = {int(p) for k, p in zip(ev["kind"], ev["prim"]) if k in (3, 4)}  # surface hit or back-face kill
+    want = {3, 7} if periodic else {3, 5}
+    assert reached <= {2, 3, 4, 5, 6, 7} and (reached & {w for w in want} or reached & {w - 1 for w in want})
+    # same primitive PAIR as the reference expects (a line's two triangles share the diagonal at z = 0)
+    assert {r // 2 for r in reached} == {w // 2 for w in want}, (reached, want)
+
+
+# ---------------------------------------------------------------------------
+# Boundary::processHit known answers of the reference ON THE DEVICE (vr_debug_process_hit)
+# ---------------------------------------------------------------------------
+def _plane_tracer(extent, delta, direction, radius, bcs, src):
+    pts, nrm = vr.io.create_plane_grid(delta, extent, direction)
+    t = vr.TraceDisk(3)
+    t.setGeometry(pts, nrm, delta, radius)
+    t.setBoundaryConditions(bcs)
+    t.setSourceDirection(src)
+    t.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+    return t
+
+
+def test_boundary_hit_known_answers_on_the_device():
+    """tests/boundaryHit/boundaryHit.cpp:68-76,128-136,188-196"""
+    eps = 1e-6
+    d = np.array([0.5, 0.0, -0.25], dtype=np.float32)
+    dist = np.float32(np.linalg.norm(d))
+    dn = d / dist
+    # reflective x wall, POS_Z: new origin (1, 0.5, 0.25), x component of the direction mirrored
+    t = _plane_tracer(1.0, 0.1, (0, 1, 2), 0.1, [BC.REFLECTIVE_BOUNDARY, BC.PERIODIC_BOUNDARY, BC.PERIODIC_BOUNDARY], TD.POS_Z)
+    o, dd, refl = t.debugProcessHit([[0.5, 0.5, 0.5]], [dn], dist, 2)
+    assert refl[0] and np.allclose(o[0], [1.0, 0.5, 0.25], atol=eps) and np.allclose(dd[0], [-dn[0], dn[1], dn[2]], atol=eps)
+    # periodic x wall: the origin wraps to x = -1, direction unchanged
+    t = _plane_tracer(1.0, 0.1, (0, 1, 2), 0.1, [BC.PERIODIC_BOUNDARY] * 3, TD.POS_Z)
+    o, dd, refl = t.debugProcessHit([[0.5, 0.5, 0.5]], [dn], dist, 2)
+    assert refl[0] and np.allclose(o[0], [-1.0, 0.5, 0.25], atol=eps) and np.allclose(dd[0], dn, atol=eps)
+    # ignore: the ray stops
+    t = _plane_tracer(1.0, 0.1, (0, 1, 2), 0.1, [BC.IGNORE_BOUNDARY] * 3, TD.POS_Z)
+    assert not t.debugProcessHit([[0.5, 0.5, 0.5]], [dn], dist, 2)[2][0]
+    # reflective z wall, POS_Y tracing, plane in x-z: new origin (0.5, 0.25, 1.0), z mirrored
+    d2 = np.array([0.0, -0.25, 0.5], dtype=np.float32)
+    dist2 = np.float32(np.linalg.norm(d2))
+    dn2 = d2 / dist2
+    t = _plane_tracer(1.0, 0.1, (0, 2, 1), 0.1, [BC.PERIODIC_BOUNDARY, BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY], TD.POS_Y)
+    o, dd, refl = t.debugProcessHit([[0.5, 0.5, 0.5]], [dn2], dist2, 6)
+    assert refl[0] and np.allclose(o[0], [0.5, 0.25, 1.0], atol=eps) and np.allclose(dd[0], [dn2[0], dn2[1], -dn2[2]], atol=eps)
+    # a wall met from outside lets the ray through (rayBoundary.hpp:33-44): origin = hit point, same direction
+    o, dd, refl = t.debugProcessHit([[0.5, 0.5, 1.5]], [[dn2[0], dn2[1], -dn2[2]]], dist2, 6)
+    assert refl[0] and np.allclose(o[0], [0.5, 0.25, 1.0], atol=eps) and np.allclose(dd[0], [dn2[0], dn2[1], -dn2[2]], atol=eps)
+
+
+def test_boundary_hit_2d_known_answers_on_the_device():
+    """tests/boundaryHit2D/boundaryHit2D.cpp:73-79,122-128,185-190,234-239"""
+    eps = 1e-6
+    vals = np.arange(-2, 2.0001, 0.5, dtype=np.float32)
+
+    def line(axis, naxis):
+        pts = np.zeros((vals.size, 3), dtype=np.float32)
+        pts[:, axis] = vals
+        nrm = np.zeros_like(pts)
+        nrm[:, naxis] = 1.0
+        return pts, nrm
+
+    pts, nrm = line(1, 0)  # points along y, normals +x, traced from POS_X
+    for bc, ynew in ((BC.REFLECTIVE_BOUNDARY, 2.0), (BC.PERIODIC_BOUNDARY, -2.0)):
+        t = vr.TraceDisk(2)
+        t.setGeometry(pts, nrm, 0.5, 0.5)
+        t.setBoundaryConditions([BC.REFLECTIVE_BOUNDARY, bc])
+        t.setSourceDirection(TD.POS_X)
+        t.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+        d = np.array([-0.5, 1.0, 0.0], dtype=np.float32)
+        dist = np.float32(np.linalg.norm(d))
+        dn = d / dist
+        o, dd, refl = t.debugProcessHit([[1.0, 1.0, 0.0]], [dn], dist, 3)
+        assert refl[0] and np.allclose(o[0], [0.5, ynew, 0.0], atol=eps)
+        assert np.allclose(dd[0], [dn[0], -dn[1], 0] if bc == BC.REFLECTIVE_BOUNDARY else dn, atol=eps)
+    pts, nrm = line(0, 1)  # points along x, normals +y, traced from POS_Y
+    for bc, xnew in ((BC.REFLECTIVE_BOUNDARY, 2.0), (BC.PERIODIC_BOUNDARY, -2.0)):
+        t = vr.TraceDisk(2)
+        t.setGeometry(pts, nrm, 0.5, 0.5)
+        t.setBoundaryConditions([bc, BC.REFLECTIVE_BOUNDARY])
+        t.setSourceDirection(TD.POS_Y)
+        t.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+        d = np.array([1.0, -0.5, 0.0], dtype=np.float32)
+        dist = np.float32(np.linalg.norm(d))
+        o, dd, refl = t.debugProcessHit([[1.0, 1.0, 0.0]], [d / dist], dist, 3)
+        assert refl[0] and np.allclose(o[0], [xnew, 0.5, 0.0], atol=eps)

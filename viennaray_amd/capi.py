@@ -93,6 +93,7 @@ SIGNATURES = {
     "vr_add_trace_info": (C.c_int, [_vp, C.POINTER(TraceInfoPOD)]),
     "vr_stream": (_vp, [_vp]),
     "vr_debug_intersect": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32, _i32p, _u32p, _fp]),
+    "vr_debug_process_hit": (C.c_int, [_vp, _fp, _fp, _fp, _u32p, C.c_uint32, _fp, _fp, _i32p]),
     "vr_debug_source_sample": (C.c_int, [_vp, _u64p, C.c_uint32, C.c_uint32, _fp, _fp]),
     "vr_debug_rng_outputs": (C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, _u64p]),
     "vr_debug_issue_rate": (C.c_int, [_vp, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_double)]),

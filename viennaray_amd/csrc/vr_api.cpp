@@ -1559,6 +1559,42 @@ int vr_debug_intersect(vr_context *c, const float *org, const float *dir, const 
   return VR_OK;
 }
 
+// Boundary::processHit on the device for hand-built hits (tests/boundaryHit, boundaryHit2D): ray (org, dir) meets wall
+// triangle primID at parameter tfar -> new origin, new (projected) direction, reflect flag
+int vr_debug_process_hit(vr_context *c, const float *org, const float *dir, const float *tfar, const uint32_t *primID,
+                         uint32_t n, float *outOrg, float *outDir, int32_t *outReflect) {
+  if (!c || !org || !dir || !tfar || !primID || !outOrg || !outDir || !outReflect)
+    return VR_E_INVALID;
+  for (uint32_t i = 0; i < n; ++i)
+    if (primID[i] > 7u)
+      return fail(c, VR_E_INVALID, "vr_debug_process_hit: boundary primID must be 0..7");
+  if (!c->prepared) {
+    int r = vr_apply_prepare(c);
+    if (r != VR_OK)
+      return r;
+  }
+  DevBuf<float> dO, dD, dT, dOo, dDo;
+  DevBuf<uint32_t> dP;
+  DevBuf<int> dR;
+  VR_HIP(c, dO.ensure((size_t)n * 3));
+  VR_HIP(c, dD.ensure((size_t)n * 3));
+  VR_HIP(c, dT.ensure(n));
+  VR_HIP(c, dP.ensure(n));
+  VR_HIP(c, dOo.ensure((size_t)n * 3));
+  VR_HIP(c, dDo.ensure((size_t)n * 3));
+  VR_HIP(c, dR.ensure(n));
+  VR_HIP(c, hipMemcpy(dO.p, org, (size_t)n * 12, hipMemcpyHostToDevice));
+  VR_HIP(c, hipMemcpy(dD.p, dir, (size_t)n * 12, hipMemcpyHostToDevice));
+  VR_HIP(c, hipMemcpy(dT.p, tfar, (size_t)n * 4, hipMemcpyHostToDevice));
+  VR_HIP(c, hipMemcpy(dP.p, primID, (size_t)n * 4, hipMemcpyHostToDevice));
+  VR_HIP(c, launch_debug_process_hit(c->params, c->geo.D, dO.p, dD.p, dT.p, dP.p, n, dOo.p, dDo.p, dR.p, c->stream));
+  VR_HIP(c, hipStreamSynchronize(c->stream));
+  VR_HIP(c, hipMemcpy(outOrg, dOo.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+  VR_HIP(c, hipMemcpy(outDir, dDo.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+  VR_HIP(c, hipMemcpy(outReflect, dR.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return VR_OK;
+}
+
 int vr_debug_source_sample(vr_context *c, const uint64_t *idx, uint32_t n, uint32_t seed, float *org, float *dir) {
   if (!c || !idx || !org || !dir)
     return VR_E_INVALID;

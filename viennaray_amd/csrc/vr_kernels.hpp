@@ -16,6 +16,9 @@ int trace_blocks_per_cu(int D, int geo, int particle, int mode);
 hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *org, const float *dir,
                                   const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t,
                                   hipStream_t s);
+hipError_t launch_debug_process_hit(const TraceParams &p, int D, const float *org, const float *dir, const float *tfar,
+                                    const unsigned *prim, unsigned n, float *outOrg, float *outDir, int *outReflect,
+                                    hipStream_t s);
 hipError_t launch_debug_rng(unsigned seed32, unsigned count, unsigned long long *scratch, unsigned long long *out,
                             hipStream_t s);
 // device-side setup (vr_setup.hip)

@@ -318,6 +318,44 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Boundary::processHit (rayBoundary.hpp:29-127): what a hit of wall triangle `prim` at hitPoint does to the
+// ray.  Shared by trace_kernel and the debug entry point that checks the reference's boundaryHit known answers.
+template <int D>
+__device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const float *__restrict__ wallS, unsigned prim,
+                                                     const V3 &hitPoint, V3 &org, V3 &rayDirection, V3 &dir,
+                                                     bool &active) {
+  const float *w = wallS + 12 * prim;
+  V3 ng = mk(w[9], w[10], w[11]);
+  if (vdot(dir, ng) > 0.f) { // back side: pass through
+    org = hitPoint;
+    return;
+  }
+  int bc, axis;
+  bool minWall;
+  if (D == 2 || prim <= 3u) {
+    bc = p.bc0;
+    axis = p.firstDir;
+    minWall = prim <= 1u;
+  } else {
+    bc = p.bc1;
+    axis = p.secondDir;
+    minWall = prim <= 5u;
+  }
+  if (bc == 0) { // REFLECTIVE, rayBoundary.hpp:261-271
+    vnormalize(ng);
+    rayDirection = reflect_specular(rayDirection, ng);
+    dir = project_dir<D>(rayDirection);
+    org = hitPoint;
+  } else if (bc == 1) { // PERIODIC: wrap to the opposite face
+    org = hitPoint;
+    const bool first = (D == 2 || prim <= 3u);
+    const float wrapTo = first ? (minWall ? p.hi1 : p.lo1) : (minWall ? p.hi2 : p.lo2);
+    setc(org, axis, wrapTo);
+  } else { // IGNORE
+    active = false;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // trace_kernel
 //   ABSORB: every hit absorbs the whole weight (sticking >= 1 everywhere), so
@@ -576,36 +614,7 @@ trace_kernel(const TraceParams p) {
             VR_COUNT(K_TERM, 1);
             active = false;
           } else {
-            const float *w = wallS + 12 * h.prim;
-            V3 ng = mk(w[9], w[10], w[11]);
-            if (vdot(dir, ng) > 0.f) { // back side: pass through
-              org = hitPoint;
-            } else {
-              int bc, axis;
-              bool minWall;
-              if (D == 2 || h.prim <= 3u) {
-                bc = p.bc0;
-                axis = p.firstDir;
-                minWall = h.prim <= 1u;
-              } else {
-                bc = p.bc1;
-                axis = p.secondDir;
-                minWall = h.prim <= 5u;
-              }
-              if (bc == 0) { // REFLECTIVE, rayBoundary.hpp:261-271
-                vnormalize(ng);
-                rayDirection = reflect_specular(rayDirection, ng);
-                dir = project_dir<D>(rayDirection);
-                org = hitPoint;
-              } else if (bc == 1) { // PERIODIC: wrap to the opposite face
-                org = hitPoint;
-                const bool first = (D == 2 || h.prim <= 3u);
-                const float wrapTo = first ? (minWall ? p.hi1 : p.lo1) : (minWall ? p.hi2 : p.lo2);
-                setc(org, axis, wrapTo);
-              } else { // IGNORE
-                active = false;
-              }
-            }
+            process_boundary_hit<D>(p, wallS, h.prim, hitPoint, org, rayDirection, dir, active);
           }
         } else {
           // geometry hit
@@ -900,6 +909,42 @@ hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *or
     hipLaunchKernelGGL((debug_intersect_kernel<0>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t);
   else
     hipLaunchKernelGGL((debug_intersect_kernel<1>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t);
+  return hipGetLastError();
+}
+
+template <int D>
+__global__ void debug_process_hit_kernel(const TraceParams p, const float *org, const float *dir, const float *tfar,
+                                         const unsigned *prim, unsigned n, float *outOrg, float *outDir, int *outReflect) {
+  __shared__ float wallS[96];
+  for (unsigned k = threadIdx.x; k < 96; k += blockDim.x)
+    wallS[k] = p.wallTable[k];
+  __syncthreads();
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  V3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]);
+  V3 rd = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+  V3 d = project_dir<D>(rd);
+  const V3 hp = mk(o.x + d.x * tfar[i], o.y + d.y * tfar[i], o.z + d.z * tfar[i]);
+  bool active = true;
+  process_boundary_hit<D>(p, wallS, prim[i], hp, o, rd, d, active);
+  outOrg[3 * i] = o.x;
+  outOrg[3 * i + 1] = o.y;
+  outOrg[3 * i + 2] = o.z;
+  outDir[3 * i] = d.x;
+  outDir[3 * i + 1] = d.y;
+  outDir[3 * i + 2] = d.z;
+  outReflect[i] = active ? 1 : 0;
+}
+
+hipError_t launch_debug_process_hit(const TraceParams &p, int D, const float *org, const float *dir, const float *tfar,
+                                    const unsigned *prim, unsigned n, float *outOrg, float *outDir, int *outReflect,
+                                    hipStream_t s) {
+  const unsigned grid = (n + 63) / 64;
+  if (D == 2)
+    hipLaunchKernelGGL((debug_process_hit_kernel<2>), dim3(grid), dim3(64), 0, s, p, org, dir, tfar, prim, n, outOrg, outDir, outReflect);
+  else
+    hipLaunchKernelGGL((debug_process_hit_kernel<3>), dim3(grid), dim3(64), 0, s, p, org, dir, tfar, prim, n, outOrg, outDir, outReflect);
   return hipGetLastError();
 }
 

@@ -438,6 +438,20 @@ class Trace:
                                                p.ctypes.data_as(C.POINTER(C.c_uint32)), _fptr(t)))
         return g, p, t
 
+    def debugProcessHit(self, org, dirn, tfar, primID):
+        """Boundary::processHit on the device: (new origins, new directions, reflect flags)"""
+        o = np.ascontiguousarray(org, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirn, dtype=np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(tfar, dtype=np.float32), (n,)))
+        p = np.ascontiguousarray(np.broadcast_to(np.asarray(primID, dtype=np.uint32), (n,)))
+        oo, do = np.empty_like(o), np.empty_like(d)
+        r = np.empty(n, dtype=np.int32)
+        self._check(self._L.vr_debug_process_hit(self._h, _fptr(o), _fptr(d), _fptr(t),
+                                                 p.ctypes.data_as(C.POINTER(C.c_uint32)), n, _fptr(oo), _fptr(do),
+                                                 r.ctypes.data_as(C.POINTER(C.c_int32))))
+        return oo, do, r.astype(bool)
+
     def debugSourceSample(self, idx, seed):
         i = np.ascontiguousarray(idx, dtype=np.uint64)
         o = np.empty((i.size, 3), dtype=np.float32)
