@@ -147,6 +147,16 @@ int vr_apply_prepare(vr_context *ctx);
 int vr_apply_launch(vr_context *ctx);
 int vr_apply_finish(vr_context *ctx);
 
+/* Multi-GPU apply() (the reference has no distributed layer): one process per GPU,
+ * geometry and BVH replicated, rank r traces the r-th contiguous share of the global ray indices
+ * (ray idx keeps its global value, so the union reproduces the single-device stream,
+ * rayTraceKernel.hpp:118-121), and the per-primitive int64 accumulators plus the seven counters
+ * are summed over the ranks by `reduce` — an in-place sum all-reduce of `count` int64 in DEVICE
+ * memory enqueued on `hipStream` (0 = ok).  vr_rccl_allreduce (viennaray_amd_rccl.h) is that
+ * callback on RCCL over xGMI.  Afterwards every rank holds the full result of Trace::apply().   */
+typedef int (*vr_allreduce_fn)(void *user, void *devInt64, size_t count, void *hipStream);
+int vr_apply_sharded(vr_context *ctx, int rank, int world, vr_allreduce_fn reduce, void *user);
+
 /* ---- results ------------------------------------------------------------- */
 uint32_t vr_num_primitives(const vr_context *ctx);
 /* getLocalData().getVectorData(0) (rayTrace.hpp:135): raw, un-normalised     */

@@ -768,7 +768,7 @@ public:
     }
     if (pSource_ && !sourceOnDevice_ && !uploadHostSource())
       return;
-    const int rc = vr_apply(ctx_);
+    const int rc = world_ > 1 ? vr_apply_sharded(ctx_, rank_, world_, reduce_, reduceUser_) : vr_apply(ctx_);
     vr_trace_info i{};
     vr_get_trace_info(ctx_, &i);
     RTInfo_.numRays = i.numRays;
@@ -861,6 +861,15 @@ public:
     useRandomSeeds_ = false;
     if (ctx_)
       check(vr_set_rng_seed(ctx_, seed));
+  }
+  /// NOT in the reference: make apply() one rank of a multi-GPU trace (one process per GPU).  This rank
+  /// traces its share of the global ray indices and `reduce` sums the int64 accumulators over the ranks
+  /// (vr_rccl_allreduce of viennaray_amd_rccl.h = RCCL over xGMI); every rank ends with the full flux.
+  void setDistributed(int rank, int world, vr_allreduce_fn reduce, void *user) {
+    rank_ = rank;
+    world_ = world;
+    reduce_ = reduce;
+    reduceUser_ = user;
   }
   /// VIENNARAY_USE_WDIST (a compile-time option of the reference, CMakeLists.txt:15) as a run-time switch
   void setUseWdist(const bool on) {
@@ -995,6 +1004,9 @@ protected:
   bool useRandomSeeds_ = true;
   unsigned rngSeed_ = 0;
   size_t numRaysPerPoint_ = 1000, numRaysFixed_ = 0;
+  int rank_ = 0, world_ = 1;
+  vr_allreduce_fn reduce_ = nullptr;
+  void *reduceUser_ = nullptr;
 };
 
 template <class NumericType, int D> class TraceDisk final : public Trace<NumericType, D> {

@@ -47,3 +47,19 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in src and "vr_oracle" not in src and "liboracle" not in src, f
+
+
+def test_rccl_library_exports_its_header():
+    """include/viennaray_amd_rccl.h: the RCCL all-reduce callback lives in a library of its own"""
+    from viennaray_amd import rccl
+    txt = open(os.path.join(ROOT, "include", "viennaray_amd_rccl.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b(vr_rccl_[a-z0-9_]+)\s*\(", txt)))
+    assert names == sorted(rccl.SYMBOLS)
+    import ctypes
+    try:
+        L = ctypes.CDLL(rccl.LIB_PATH)
+    except OSError as e:  # librccl needs the ROCm runtime libraries; present in this image
+        pytest.skip(str(e))
+    for n in names:
+        assert hasattr(L, n), n

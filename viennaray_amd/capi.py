@@ -73,6 +73,7 @@ SIGNATURES = {
     "vr_apply_prepare": (C.c_int, [_vp]),
     "vr_apply_launch": (C.c_int, [_vp]),
     "vr_apply_finish": (C.c_int, [_vp]),
+    "vr_apply_sharded": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "vr_num_primitives": (C.c_uint32, [_vp]),
     "vr_get_flux": (C.c_int, [_vp, _fp, C.c_uint32]),
     "vr_get_flux_f64": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_uint32]),

@@ -1269,6 +1269,50 @@ int vr_apply(vr_context *c) {
   return vr_apply_finish(c);
 }
 
+// Multi-GPU apply() behind the C ABI: this rank traces its contiguous share of the
+// global ray indices, then the per-primitive int64 accumulators (exact, order-independent) and the
+// seven counters are summed over all ranks by the caller's collective — RCCL over xGMI through
+// vr_rccl_allreduce (libviennaray_amd_rccl.so), or anything else with the same signature.  Every
+// rank ends with the full flux, bit-identical to the single-device run; runNumber advances on
+// every rank (also one whose share is empty), so later applies keep using the same seeds.
+int vr_apply_sharded(vr_context *c, int rank, int world, vr_allreduce_fn reduce, void *user) {
+  if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !reduce))
+    return fail(c, VR_E_INVALID, "vr_apply_sharded: bad argument");
+  c->rayFirst = 0;
+  c->rayCount = 0;
+  int r = vr_apply_prepare(c); // (also yields the total number of rays of this apply)
+  if (r != VR_OK)
+    return r;
+  const uint64_t total = c->numRaysLast;
+  const uint64_t first = total * (uint64_t)rank / (uint64_t)world;
+  const uint64_t last = total * (uint64_t)(rank + 1) / (uint64_t)world;
+  const uint32_t N = c->geo.numPrims;
+  if (last > first) {
+    c->rayFirst = first;
+    c->rayCount = last - first;
+    r = vr_apply_prepare(c);
+    if (r == VR_OK)
+      r = vr_apply_launch(c);
+    c->rayFirst = 0;
+    c->rayCount = 0;
+    if (r != VR_OK)
+      return r;
+  } else {
+    VR_HIP(c, hipMemsetAsync(c->fluxOut(), 0, (size_t)N * c->numData * 8, c->stream));
+    VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64 * 8, c->stream));
+    VR_HIP(c, hipEventRecord(c->ev0, c->stream));
+    VR_HIP(c, hipEventRecord(c->ev1, c->stream));
+    c->numBatches = 0;
+    c->launched = true;
+  }
+  if (world > 1) {
+    if (reduce(user, c->fluxOut(), (size_t)N * c->numData, (void *)c->stream) != 0 ||
+        reduce(user, c->dCounters.p, 8, (void *)c->stream) != 0)
+      return fail(c, VR_E_HIP, "vr_apply_sharded: the all-reduce callback failed");
+  }
+  return vr_apply_finish(c);
+}
+
 // ---- results --------------------------------------------------------------------
 uint32_t vr_num_primitives(const vr_context *c) { return c ? c->geo.numPrims : 0; }
 

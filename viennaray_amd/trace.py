@@ -347,6 +347,15 @@ class Trace:
         self._check(self._L.vr_apply(self._h))
         self._collect()
 
+    def applySharded(self, rank, world, reduce_fn=None, user=None):
+        """vr_apply_sharded: this rank's share of the rays, then `reduce_fn(user, devPtr, count, stream)` (a
+        ctypes function pointer, e.g. vr_rccl_allreduce) sums accumulators and counters over the ranks."""
+        if self._particle is None:
+            raise VrError("No particle was specified in rayTrace. Aborting.")
+        fn = C.cast(reduce_fn, C.c_void_p) if reduce_fn is not None else None
+        self._check(self._L.vr_apply_sharded(self._h, int(rank), int(world), fn, user))
+        self._collect()
+
     def applyPrepare(self):
         self._check(self._L.vr_apply_prepare(self._h))
 
