@@ -1138,56 +1138,69 @@ void createPlaneGrid(const NumericType gridDelta, const NumericType extent, cons
 template <typename NumericType, int D = 3, typename FluxType = NumericType>
 void writeVTK(const std::string &filename, const std::vector<Vec3D<NumericType>> &points,
               const std::vector<FluxType> &flux) {
+  // byte for byte the reference's output (rayUtil.hpp:413-449): each coordinate is followed by a
+  // blank, |flux| < 1e-6 prints as 0
   std::ofstream f(filename.c_str());
   f << "# vtk DataFile Version 2.0\n" << D << "D Surface\nASCII\nDATASET UNSTRUCTURED_GRID\n";
   f << "POINTS " << points.size() << " float\n";
-  for (auto const &p : points)
-    f << p[0] << " " << p[1] << " " << p[2] << "\n";
+  for (auto const &p : points) {
+    for (int j = 0; j < 3; j++)
+      f << static_cast<float>(p[j]) << " ";
+    f << "\n";
+  }
   f << "CELLS " << points.size() << " " << points.size() * 2 << "\n";
   for (size_t i = 0; i < points.size(); ++i)
-    f << "1 " << i << "\n";
+    f << 1 << " " << i << "\n";
   f << "CELL_TYPES " << points.size() << "\n";
   for (size_t i = 0; i < points.size(); ++i)
-    f << "1\n";
+    f << 1 << "\n";
   f << "CELL_DATA " << flux.size() << "\nSCALARS flux float\nLOOKUP_TABLE default\n";
-  for (auto v : flux)
-    f << v << "\n";
+  for (size_t j = 0; j < flux.size(); ++j)
+    f << ((std::abs(flux[j]) < 1e-6) ? 0.0 : flux[j]) << "\n";
 }
 
-// rayUtil.hpp:451-555: VTK PolyData (lines for D == 2, polygons for D == 3) + cell data
+// rayUtil.hpp:451-555: VTK PolyData (lines for D == 2, polygons for D == 3); the flux goes to the
+// points if its length is the point count, else to the cells if it is the element count
 template <typename NumericType, int D = 3, typename ResultType = NumericType>
 void writeVTP(const std::string &filename, const std::vector<Vec3D<NumericType>> &points,
               const std::vector<VectorType<unsigned, D>> &elements, const std::vector<ResultType> &flux) {
   std::ofstream f(filename.c_str());
   if (!f.is_open())
     return;
+  const size_t nPoints = points.size(), nElements = elements.size();
   f << "<?xml version=\"1.0\"?>\n<VTKFile type=\"PolyData\" version=\"0.1\" byte_order=\"LittleEndian\">\n  <PolyData>\n";
-  f << "    <Piece NumberOfPoints=\"" << points.size() << "\" NumberOfVerts=\"0\" NumberOfLines=\""
-    << (D == 2 ? elements.size() : 0) << "\" NumberOfStrips=\"0\" NumberOfPolys=\"" << (D == 2 ? 0 : elements.size())
+  f << "    <Piece NumberOfPoints=\"" << nPoints << "\" NumberOfVerts=\"0\" NumberOfLines=\"" << (D == 2 ? nElements : 0)
+    << "\" NumberOfStrips=\"0\" NumberOfPolys=\"" << (D == 2 ? 0 : nElements)
     << "\">\n      <Points>\n        <DataArray type=\"Float32\" NumberOfComponents=\"3\" format=\"ascii\">\n";
   for (auto const &p : points)
-    f << (float)p[0] << " " << (float)p[1] << " " << (float)p[2] << "\n";
+    f << static_cast<float>(p[0]) << " " << static_cast<float>(p[1]) << " " << static_cast<float>(p[2]) << "\n";
   f << "        </DataArray>\n      </Points>\n      " << (D == 2 ? "<Lines>" : "<Polys>")
     << "\n        <DataArray type=\"Int32\" Name=\"connectivity\" format=\"ascii\">\n";
   for (auto const &e : elements) {
     for (int j = 0; j < D; ++j)
-      f << (int)e[j] << " ";
+      f << static_cast<int>(e[j]) << " ";
     f << "\n";
   }
   f << "        </DataArray>\n        <DataArray type=\"Int32\" Name=\"offsets\" format=\"ascii\">\n";
-  for (size_t i = 1; i <= elements.size(); ++i)
-    f << i * D << "\n";
+  int offset = 0;
+  for (size_t i = 0; i < nElements; ++i) {
+    offset += D;
+    f << offset << "\n";
+  }
   f << "        </DataArray>\n      " << (D == 2 ? "</Lines>" : "</Polys>") << "\n";
-  if (flux.size() == elements.size() || flux.size() == points.size()) {
-    const bool cell = flux.size() == elements.size();
-    f << "      " << (cell ? "<CellData" : "<PointData") << " Scalars=\"flux\">\n"
+  if (flux.size() == nPoints || flux.size() == nElements) {
+    const bool point = flux.size() == nPoints;
+    f << "      " << (point ? "<PointData" : "<CellData") << " Scalars=\"flux\">\n"
       << "        <DataArray type=\"Float32\" Name=\"flux\" format=\"ascii\">\n";
-    for (auto v : flux)
-      f << (float)v << "\n";
-    f << "        </DataArray>\n      " << (cell ? "</CellData>" : "</PointData>") << "\n";
-  } else {
+    for (size_t i = 0; i < flux.size(); ++i)
+      f << ((std::abs(flux[i]) < 1e-6) ? 0.0f : static_cast<float>(flux[i])) << "\n";
+    f << "        </DataArray>\n      " << (point ? "</PointData>" : "</CellData>") << "\n";
+  } else if (!flux.empty()) {
     std::cerr << "writeVTP: flux size does not match points or polys; skipping data\n";
   }
   f << "    </Piece>\n  </PolyData>\n</VTKFile>\n";
+}
+inline void writeVTP(TriangleMesh const &mesh, const std::string &filename, const std::vector<double> &flux) {
+  writeVTP<float, 3>(filename, mesh.nodes, mesh.triangles, flux);
 }
 } // namespace rayInternal

@@ -9,6 +9,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
+#include <iterator>
+#include <string>
 
 using namespace viennaray;
 
@@ -95,6 +98,48 @@ int main(int argc, char **argv) {
     CHECK(tri.nodes.size() == 262 && tri.triangles.size() == 256);
     CHECK(tri.nodes[0][2] == 0.1f && tri.nodes[1][2] == -0.1f);
     CHECK(tri.triangles[0][0] == 2 * lineMesh.lines[0][0] && tri.triangles[0][2] == tri.triangles[0][0] + 1);
+  }
+  { // writeVTK / writeVTP: byte for byte what rayUtil.hpp:413-555 writes for these inputs
+    auto slurp = [](const std::string &fn) {
+      std::ifstream f(fn);
+      return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    };
+    const std::string dir = argc > 2 ? argv[2] : "/tmp";
+    std::vector<Vec3D<float>> pts = {{0.f, 0.5f, -1.f}, {1.25f, 2.f, 3.f}, {1e-3f, 0.f, 7.f}};
+    std::vector<float> flux = {1.5f, 5e-7f, 2.f};
+    rayInternal::writeVTK<float, 3>(dir + "/u.vtk", pts, flux);
+    const std::string vtk = "# vtk DataFile Version 2.0\n3D Surface\nASCII\nDATASET UNSTRUCTURED_GRID\nPOINTS 3 float\n"
+                            "0 0.5 -1 \n1.25 2 3 \n0.001 0 7 \nCELLS 3 6\n1 0\n1 1\n1 2\nCELL_TYPES 3\n1\n1\n1\n"
+                            "CELL_DATA 3\nSCALARS flux float\nLOOKUP_TABLE default\n1.5\n0\n2\n";
+    CHECK(slurp(dir + "/u.vtk") == vtk);
+    std::vector<VectorType<unsigned, 3>> tris = {{0u, 1u, 2u}};
+    std::vector<double> cellFlux = {0.25};
+    rayInternal::writeVTP<float, 3>(dir + "/u.vtp", pts, tris, cellFlux);
+    const std::string head = "<?xml version=\"1.0\"?>\n<VTKFile type=\"PolyData\" version=\"0.1\" byte_order=\"LittleEndian\">\n"
+                             "  <PolyData>\n";
+    const std::string body3 =
+        "    <Piece NumberOfPoints=\"3\" NumberOfVerts=\"0\" NumberOfLines=\"0\" NumberOfStrips=\"0\" NumberOfPolys=\"1\">\n"
+        "      <Points>\n        <DataArray type=\"Float32\" NumberOfComponents=\"3\" format=\"ascii\">\n"
+        "0 0.5 -1\n1.25 2 3\n0.001 0 7\n        </DataArray>\n      </Points>\n      <Polys>\n"
+        "        <DataArray type=\"Int32\" Name=\"connectivity\" format=\"ascii\">\n0 1 2 \n        </DataArray>\n"
+        "        <DataArray type=\"Int32\" Name=\"offsets\" format=\"ascii\">\n3\n        </DataArray>\n      </Polys>\n"
+        "      <CellData Scalars=\"flux\">\n        <DataArray type=\"Float32\" Name=\"flux\" format=\"ascii\">\n0.25\n"
+        "        </DataArray>\n      </CellData>\n";
+    const std::string tail = "    </Piece>\n  </PolyData>\n</VTKFile>\n";
+    CHECK(slurp(dir + "/u.vtp") == head + body3 + tail);
+    // D == 2: lines; a flux as long as the point list goes to the points (it takes precedence)
+    std::vector<VectorType<unsigned, 2>> lines = {{0u, 1u}, {1u, 2u}};
+    std::vector<float> pointFlux = {1.f, 1e-9f, 3.f};
+    rayInternal::writeVTP<float, 2>(dir + "/u2.vtp", pts, lines, pointFlux);
+    const std::string body2 =
+        "    <Piece NumberOfPoints=\"3\" NumberOfVerts=\"0\" NumberOfLines=\"2\" NumberOfStrips=\"0\" NumberOfPolys=\"0\">\n"
+        "      <Points>\n        <DataArray type=\"Float32\" NumberOfComponents=\"3\" format=\"ascii\">\n"
+        "0 0.5 -1\n1.25 2 3\n0.001 0 7\n        </DataArray>\n      </Points>\n      <Lines>\n"
+        "        <DataArray type=\"Int32\" Name=\"connectivity\" format=\"ascii\">\n0 1 \n1 2 \n        </DataArray>\n"
+        "        <DataArray type=\"Int32\" Name=\"offsets\" format=\"ascii\">\n2\n4\n        </DataArray>\n      </Lines>\n"
+        "      <PointData Scalars=\"flux\">\n        <DataArray type=\"Float32\" Name=\"flux\" format=\"ascii\">\n1\n0\n3\n"
+        "        </DataArray>\n      </PointData>\n";
+    CHECK(slurp(dir + "/u2.vtp") == head + body2 + tail);
   }
   std::puts("facade units ok");
   return 0;

@@ -61,12 +61,13 @@ def test_line_mesh_conversion():
 
 def test_cpp_facade_units(tmp_path):
     """the same known answers on the header-only C++ façade (links without the HIP library:
-    nothing in it instantiates Trace::apply)"""
+    nothing in it instantiates Trace::apply), plus the VTK / VTP writers byte for byte
+    (rayUtil.hpp:413-555)"""
     exe = tmp_path / "facade_units"
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include", "viennaray_amd"),
                            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "aux", "facade_units.cpp"),
                            "-o", str(exe)])
-    out = subprocess.run([str(exe), os.path.join(DATA, "lineMesh.dat")], capture_output=True, text=True)
+    out = subprocess.run([str(exe), os.path.join(DATA, "lineMesh.dat"), str(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "facade units ok" in out.stdout, out.stdout + out.stderr
 
 
