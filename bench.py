@@ -348,7 +348,7 @@ def main():
 
     if rank == 0:
         mode = tr.traceMode()
-        kernel_name = f"trace_kernel<3,0,{0 if mode else tr._particle.kind},{mode}>"
+        kernel_name = f"trace_kernel<3,0,{0 if mode in (1, 2) else tr._particle.kind},{mode}>"
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
         kavg = float(np.mean(pipe_ms))    # whole device pipeline: gen + trace (+ memsets)
@@ -370,7 +370,8 @@ def main():
                                       f"{args.rays} rays per GPU per step") + ", seed 12345",
                        "rays_per_gpu": rays_rank, "total_rays": total_rays, "grid": n, "sticking": args.sticking,
                        "kernel_mode": {0: "general (reflection + roulette + RNG)", 1: "absorbing, flat scene",
-                                       2: "absorbing, structured scene"}[mode],
+                                       2: "absorbing, structured scene",
+                                       3: "general, flat scene (packet-query crediting)"}[mode],
                        "parallelism": f"ray-range shards x{world}, BVH replicated, int64 flux all-reduce"},
             "device_pipeline_ms": round(kavg, 4), "trace_kernel_ms": round(tavg, 4), "gen_kernel_ms": round(gavg, 4),
             "segments_per_step": int(np.mean(segs)), "Msegments_per_s": round(np.mean(segs) / (kavg * 1e-3) / 1e6, 2),

@@ -478,6 +478,7 @@ SCHEDULING_KNOBS = [
     {"VR_PQ_CAND": "63", "VR_PQ_FRONTIER": "64"},     # box queries run to the end even where they do not pay
     {"VR_PQ_CAND": "2"},                              # ... or give up half way (found hits stay valid)
     {"VR_PQ_FRONTIER": "1"},
+    {"VR_GENERAL_FLAT": "1"}, {"VR_GENERAL_FLAT": "0"},  # packet-query crediting on / off in the general kernel
 ]
 
 
@@ -780,7 +781,7 @@ def test_c2_million_disk_plane_matches_oracle(sticking):
     o.set_ray_range(0, 10_000_000)
     err, gi = compare(t, o, exact_flux=(sticking == 1.0))
     assert gi["numRays"] == 100_000_000 and gi["geometryHits"] >= 9_990_000
-    assert t.traceMode() == (1 if sticking == 1.0 else 0)
+    assert t.traceMode() == (1 if sticking == 1.0 else 3)
 
 
 def test_c2_full_size_properties():

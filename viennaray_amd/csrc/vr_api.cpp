@@ -948,7 +948,12 @@ int vr_apply_prepare(vr_context *c) {
   {
     // absorbing particles: a (nearly) flat surface is served by packets alone; a structured one
     // ends most rounds in per-lane walks and wants the straggler carry-over (MODE 2)
-    c->traceMode = !c->absorb ? 0 : (c->keyShare >= 0.95f ? 1 : 2);
+    // general particles on a flat surface of disks: the general kernel with the packet query's crediting (MODE 3)
+    c->traceMode = !c->absorb ? ((c->keyShare >= 0.95f && c->geo.geo == 0 && c->kernelParticle != (int)P_EXT) ? 3 : 0)
+                              : (c->keyShare >= 0.95f ? 1 : 2);
+    if (const char *e = std::getenv("VR_GENERAL_FLAT"))
+      if (!c->absorb && c->geo.geo == 0 && c->kernelParticle != (int)P_EXT)
+        c->traceMode = std::atoi(e) ? 3 : 0;
     if (const char *e = std::getenv("VR_ABSORB_CARRY"))
       if (c->absorb)
         c->traceMode = std::atoi(e) ? 2 : 1;
@@ -988,7 +993,7 @@ int vr_apply_prepare(vr_context *c) {
   p.pqMaxFrontier = 12;
   if (const char *e = std::getenv("VR_PQ_FRONTIER"))
     p.pqMaxFrontier = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
-  p.pqMaxCand = 40;
+  p.pqMaxCand = 24;
   if (const char *e = std::getenv("VR_PQ_CAND"))
     p.pqMaxCand = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   {
@@ -998,6 +1003,8 @@ int vr_apply_prepare(vr_context *c) {
       p.sceneHi[k] = c->sceneHi[k];
       scale = std::max(scale, std::max(std::fabs(c->sceneLo[k]), std::fabs(c->sceneHi[k])));
     }
+    p.nbDist = 2 * c->geo.diskRadius;
+    p.geoD = D;
     p.pqPad = 1e-5f * scale; // >> the rounding of the clip (1e-7 relative); the boxes carry their own 4e-6 pad
   }
   p.nbOff = c->dNbOff.p;

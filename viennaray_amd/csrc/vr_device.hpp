@@ -595,14 +595,38 @@ __device__ __forceinline__ void wave_minmax6(float &a, float &b, float &c, float
   f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 63));
 }
 
+// v_writelane_b32: lane `dstLane` of `reg` := the wave-uniform value `val`
+__device__ __forceinline__ unsigned lane_write(unsigned reg, unsigned val, int dstLane) {
+  const unsigned sv = (unsigned)__builtin_amdgcn_readfirstlane((int)val);
+  const int sl = __builtin_amdgcn_readfirstlane(dstLane);
+  // (gfx9 allows one SGPR on the constant bus: the lane select goes through M0)
+  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(sv), "s"(sl) : "m0");
+  return reg;
+}
+__device__ __forceinline__ bool local_disc_hit(const V3 &ro, const V3 &rd, const float4 &c4, const V3 &n);
+
 __device__ __forceinline__ float lane_bcast(float v, int srcLane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srcLane));
 }
 
+// What a completed packet query leaves behind for the crediting of disks (pq_credit, vr_trace.hip):
+// candidate c's leaf position and centre live in LANE c of four registers (written with
+// v_writelane, read back wave-uniformly with v_readlane: no memory), and bit c of each lane's
+// `local` says whether that lane's ray passes the neighbour test on candidate c
+// (checkLocalIntersection, rayTraceKernel.hpp:462-507).  Every disk a ray can be credited to is
+// among the candidates: the test only passes where the ray crosses the disk, the disk lies in the
+// scene box, and Q covers every participating ray from its origin to where it leaves that box.
+struct PqCands {
+  unsigned pos;  // lane c: leaf position of candidate c
+  float cx, cy, cz;
+  unsigned long long local;
+  unsigned count; // wave-uniform
+};
+
 // lst: 128 dwords of LDS private to this wave
-template <int GEO>
+template <int GEO, bool CREDIT>
 __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
-                                              HitRec &h, volatile unsigned *lst VR_DIAG_ARGS) {
+                                              HitRec &h, volatile unsigned *lst, PqCands &cd VR_DIAG_ARGS) {
   const unsigned lane = threadIdx.x & 63u;
   // the ray's stretch inside the scene box
   const V3 inv = safe_inverse(d);
@@ -612,10 +636,15 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   const float tIn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
   const float tOut = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
   const bool valid = part && tIn <= tOut;
+  cd.count = 0;
+  cd.local = 0ull;
   if (!ballot64(valid))
     return true; // nobody reaches the scene box: every ray misses the geometry
   const float big = 3.0e38f;
-  const float ax = o.x + d.x * tIn, ay = o.y + d.y * tIn, az = o.z + d.z * tIn;
+  // (Q starts at the ray's origin where that lies inside the box, not at tnear: the neighbour test
+  //  accepts any t > 0)
+  const float tQ = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+  const float ax = o.x + d.x * tQ, ay = o.y + d.y * tQ, az = o.z + d.z * tQ;
   const float bx = o.x + d.x * tOut, by = o.y + d.y * tOut, bz = o.z + d.z * tOut;
   float qlx = valid ? fminf(ax, bx) : big, qly = valid ? fminf(ay, by) : big, qlz = valid ? fminf(az, bz) : big;
   float qhx = valid ? fmaxf(ax, bx) : -big, qhy = valid ? fmaxf(ay, by) : -big, qhz = valid ? fmaxf(az, bz) : -big;
@@ -665,6 +694,35 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   // last level: the frontier's children are primitives.  Lanes load the RECORDS of a node's
   // (<= 64) primitives, keep those whose bounds meet Q, and every kept record is broadcast from
   // its lane to the whole wave for the exact test: no separate box level, no dependent record fetch.
+  // how many candidates are there?  (boxes only, before any exact test: a packet over a relief as
+  // deep as it is wide meets dozens of primitives, and for that the slab-test packet or the
+  // per-lane walk is cheaper — give up with nothing touched)
+  if (nF >= 3u) { // (one or two leaf nodes: the usual case of a compact packet, not worth the extra pass)
+    unsigned total = 0;
+    for (unsigned j = 0; j < nF; ++j) {
+      const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)fFirst, (int)j);
+      const unsigned cnt = (unsigned)__builtin_amdgcn_readlane((int)fCnt, (int)j) & 0x7FFFFFFFu;
+      bool cand = false;
+      if (lane < cnt) {
+        const unsigned q = first + lane;
+        if (GEO == 0) {
+          const float4 r0 = prims[2 * (size_t)q];
+          cand = r0.x - r0.w <= qhx && r0.x + r0.w >= qlx && r0.y - r0.w <= qhy && r0.y + r0.w >= qly &&
+                 r0.z - r0.w <= qhz && r0.z + r0.w >= qlz;
+        } else {
+          const float4 r0 = prims[4 * (size_t)q], r1 = prims[4 * (size_t)q + 1], r2 = prims[4 * (size_t)q + 2];
+          const float v1x = r0.x - r1.x, v1y = r0.y - r1.y, v1z = r0.z - r1.z;
+          const float v2x = r0.x + r2.x, v2y = r0.y + r2.y, v2z = r0.z + r2.z;
+          cand = fminf(r0.x, fminf(v1x, v2x)) <= qhx && fmaxf(r0.x, fmaxf(v1x, v2x)) >= qlx &&
+                 fminf(r0.y, fminf(v1y, v2y)) <= qhy && fmaxf(r0.y, fmaxf(v1y, v2y)) >= qly &&
+                 fminf(r0.z, fminf(v1z, v2z)) <= qhz && fmaxf(r0.z, fmaxf(v1z, v2z)) >= qlz;
+        }
+      }
+      total += (unsigned)__popcll(ballot64(cand));
+    }
+    if (total > p.pqMaxCand)
+      return false;
+  }
   unsigned tests = 0;
   for (unsigned j = 0; j < nF; ++j) {
     const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)fFirst, (int)j);
@@ -708,6 +766,18 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
         const unsigned orig = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(r1.w), k);
         const bool ok = hit_disc(o, d, tnear, c4, n, t);
         hit_update(h, part && ok, t, orig, qq);
+        if (CREDIT) {
+          const int c = (int)tests;
+          cd.pos = lane_write(cd.pos, qq, c);
+          cd.cx = __uint_as_float(lane_write(__float_as_uint(cd.cx), __float_as_uint(c4.x), c));
+          cd.cy = __uint_as_float(lane_write(__float_as_uint(cd.cy), __float_as_uint(c4.y), c));
+          cd.cz = __uint_as_float(lane_write(__float_as_uint(cd.cz), __float_as_uint(c4.z), c));
+          // (a wave-wide early out between the cheap sign tests and the division / distance part of
+          //  these two tests was measured: the extra votes and branches cost more than they save)
+          if (part && local_disc_hit(o, d, c4, n))
+            cd.local |= 1ull << c;
+          cd.count = tests + 1u;
+        }
       } else {
         const V3 v0 = mk(lane_bcast(r0.x, k), lane_bcast(r0.y, k), lane_bcast(r0.z, k));
         const V3 e1 = mk(lane_bcast(r1.x, k), lane_bcast(r1.y, k), lane_bcast(r1.z, k));
@@ -717,8 +787,8 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
         const bool ok = hit_tri(o, d, tnear, v0, e1, e2, Ng, t);
         hit_update(h, part && ok, t, orig, qq);
       }
-      if (++tests > p.pqMaxCand)
-        return false; // too many candidates for this to pay: the hits found so far are real, the walk goes on from them
+      if (++tests > 2u * p.pqMaxCand)
+        return false; // (only reachable with <= 2 leaf nodes: the hits found so far are real, the walk goes on from them)
     }
   }
   return true;

@@ -92,6 +92,8 @@ void host_set_disks(HostGeometry &g, const float *pts, const float *nrm, uint32_
       d[1] = p[1];
       d[2] = D == 2 ? 0.f : p[2];
       d[3] = g.diskRadius;
+      if (D == 2)
+        g.points3[3 * (size_t)i + 2] = 0.f; // (2-D: the z column is ignored, rayGeometryDisk.hpp:148-151)
       for (int k = 0; k < D; ++k) { // (thread-local: the shared arrays would ping-pong between cores)
         lmin[k] = std::min(lmin[k], p[k]);
         lmax[k] = std::max(lmax[k], p[k]);

@@ -366,15 +366,24 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 //  MI355X_MICROARCH.md; 80 keeps 8 blocks resident)
 // MODE 0: general kernel.  MODE 1: absorbing, flat scene (packets carry the load).  MODE 2:
 // absorbing, structured scene (most rounds end in per-lane walks): straggler carry-over on.
+// MODE 3: general kernel for a flat scene: like 0, with the packet query's wave-uniform crediting.
 template <int D, int GEO, int PARTICLE, int MODE>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
 __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 8 : (MODE == 2 ? 7 : 6), MODE == 1 ? 8 : (MODE == 2 ? 7 : 6)))) void
 trace_kernel(const TraceParams p) {
-  constexpr bool ABSORB = MODE != 0;
+  constexpr bool ABSORB = MODE == 1 || MODE == 2;
   // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
   // extended kernel — particle kind, data labels, WDIST crediting and mean-free-path scattering
   // decided at run time from TraceParams (vr_particles.hpp)
   constexpr bool EXT = PARTICLE == P_EXT;
+  // packet-query rounds credit disks wave-uniformly from the candidate list (pq_credit) instead of
+  // walking the neighbour CSR per lane
+  constexpr bool PQ_CREDIT = GEO == 0 && !EXT && (MODE == 1 || MODE == 3);
+  PqCands cands;
+  cands.pos = 0u;
+  cands.cx = cands.cy = cands.cz = 0.f;
+  cands.local = 0ull;
+  cands.count = 0u;
   // CARRY: lanes whose BVH walk is still under way when most of the wave is done keep
   // their cursor over the state-machine / refill phase (see the round structure below).
   // The absorbing kernel for flat scenes does without: its rounds are packets, and the extra
@@ -532,13 +541,15 @@ trace_kernel(const TraceParams p) {
     const bool usePacket =
         !(p.debugFlags & 32u) && carried == 0ull && packetSkip == 0 && __popcll(ballot64(active)) >= 8;
     bool packetDone = false;
+    bool pqCredit = false; // this round's surface hits are credited from the packet's candidate list
     if (usePacket && p.wide && !(p.debugFlags & 128u)) {
       // first choice: the box query (one wide-tree search for the whole wave)
       if (pqSkip == 0) {
         if (active) {
           DIAG(12);
         }
-        packetDone = pq_hit_packet<GEO>(p, active, org, dir, tnear, h, pqS + (tid >> 6) * 128u VR_DIAG_PASS);
+        packetDone = pq_hit_packet<GEO, PQ_CREDIT>(p, active, org, dir, tnear, h, pqS + (tid >> 6) * 128u, cands VR_DIAG_PASS);
+        pqCredit = PQ_CREDIT && packetDone;
         pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
         pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;
         if (packetDone) {
@@ -584,6 +595,8 @@ trace_kernel(const TraceParams p) {
       }
     }
 
+    bool creditLane = false;
+    u64 creditW = 0;
     if (fin) {
       DIAG(5);
       // ---- the reference's state machine for this segment (rayTraceKernel.hpp:169-335) ----
@@ -638,7 +651,10 @@ trace_kernel(const TraceParams p) {
             VR_COUNT(K_GEO, 1);
             DIAG(11);
             const u64 wfx = weight_fx(rayWeight);
-            if (!EXT) {
+            if (PQ_CREDIT && pqCredit) {
+              creditLane = true; // credited after the state machine, for the whole wave at once (pq_credit)
+              creditW = wfx;
+            } else if (!EXT) {
               // surfaceCollision, rayParticle.hpp:148-156
               if (!(p.debugFlags & 1u)) {
                 if (aggregate)
@@ -757,6 +773,39 @@ trace_kernel(const TraceParams p) {
       }
       start = active; // still alive: the next segment begins in the next round
     }
+    if (PQ_CREDIT && pqCredit && !(p.debugFlags & 1u)) {
+      // ---- surfaceCollision for the round's surface hits, candidate by candidate (wave-uniform):
+      // a lane credits candidate q if q is its closest disk, or q is a neighbour of that disk
+      // (centres within nbDist: the relation the CSR was built from, rayPointNeighborhood.hpp:287-298,
+      // evaluated on the same floats) and its ray passes the neighbour test on q.  All lanes
+      // crediting q add to ONE address: a single atomic (absorbing: count x unit weight).
+      if (ballot64(creditLane)) {
+        float px = 0.f, py = 0.f, pz = 0.f; // centre of this lane's closest disk
+        for (unsigned c = 0; c < cands.count; ++c) {
+          const bool mine = h.pos == (unsigned)__builtin_amdgcn_readlane((int)cands.pos, (int)c);
+          px = mine ? lane_bcast(cands.cx, (int)c) : px;
+          py = mine ? lane_bcast(cands.cy, (int)c) : py;
+          pz = mine ? lane_bcast(cands.cz, (int)c) : pz;
+        }
+        const float dist = p.nbDist, dist2 = dist * dist;
+        for (unsigned c = 0; c < cands.count; ++c) {
+          DIAG(6);
+          const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)cands.pos, (int)c);
+          const float dx = px - lane_bcast(cands.cx, (int)c), dy = py - lane_bcast(cands.cy, (int)c),
+                      dz = pz - lane_bcast(cands.cz, (int)c);
+          bool near = fabsf(dx) <= dist && fabsf(dy) <= dist && (p.geoD == 2 || fabsf(dz) <= dist);
+          near = near && ((dx * dx + dy * dy) + dz * dz) <= dist2;
+          const bool sel = creditLane && (h.pos == q || (near && ((cands.local >> c) & 1ull)));
+          if (ABSORB) {
+            const unsigned long long m = ballot64(sel);
+            if (m && lane == (unsigned)(__ffsll((long long)m) - 1))
+              atomicAdd(&fluxAcc[q], (u64)__popcll(m) * 1099511627776ull); // unit weights: count x 2^40
+          } else {
+            credit_aggregated(fluxAcc, sel, q, creditW);
+          }
+        }
+      }
+    }
   }
 
 #ifdef VR_DIAG
@@ -828,6 +877,8 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 1>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 2)
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 2>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
+    hipLaunchKernelGGL((trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else
     hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   return hipGetLastError();
@@ -855,7 +906,7 @@ template <class F> static auto dispatch_variant(int D, int geo, int particle, F 
 
 hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int mode, unsigned grid,
                         hipStream_t s) {
-  if (mode != 0)
+  if (mode == 1 || mode == 2)
     particle = 0; // the reflection model is unobservable: one instantiation serves all
   return dispatch_variant(D, geo, particle, [&](auto d, auto g, auto pt) {
     return launch_trace_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(p, mode, grid, s);
@@ -869,13 +920,15 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode) {
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 1>, VR_BLOCK, 0);
   else if (mode == 2)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 2>, VR_BLOCK, 0);
+  else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>, VR_BLOCK, 0);
   else
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 0>, VR_BLOCK, 0);
   return e == hipSuccess ? nb : 2;
 }
 
 int trace_blocks_per_cu(int D, int geo, int particle, int mode) {
-  if (mode != 0)
+  if (mode == 1 || mode == 2)
     particle = 0;
   return dispatch_variant(D, geo, particle, [&](auto d, auto g, auto pt) {
     return occ_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(mode);

@@ -52,6 +52,8 @@ struct TraceParams {
   uint32_t pqMaxFrontier, pqMaxCand;   // give-up thresholds of the packet query
   float sceneLo[3], sceneHi[3];        // root box of the BVH (every padded primitive box)
   float pqPad;                         // outward padding of the packet's box (float rounding of the clip)
+  float nbDist;                        // neighbourhood radius = 2 x disk radius (rayGeometryDisk.hpp:191-192)
+  int32_t geoD;                        // dimension of the geometry (2: z does not enter the neighbour test's boxes)
   const uint32_t *nbOff;      // [numPrims+1], disk neighbourhood CSR (leaf order)
   const uint32_t *nbIds;      // leaf positions
   const float *primSticking;  // optional [numPrims] (leaf order) or nullptr
