@@ -364,6 +364,19 @@ __device__ __forceinline__ void hit_update(HitRec &h, bool ok, float t, unsigned
   }
 }
 
+// Conservative pre-test of a disc from its first record word {c, r} alone: a ray can only pass
+// hit_disc / local_disc_hit if its LINE comes within r of the centre and the disc is not entirely
+// behind the origin.  The per-lane paths are bound by the vector memory pipeline (one address per
+// clock per CU for scattered gathers), so a disc's second word (normal, id) is only
+// fetched by the lanes that pass.  Margins cover the rounding of the cancellation in q (a few ulp
+// of |c - o|^2); a pass decides nothing, the exact test follows.
+__device__ __forceinline__ bool disc_may_hit(const V3 &o, const V3 &d, float invDD, const float4 &c4) {
+  const V3 oc = V3{c4.x - o.x, c4.y - o.y, c4.z - o.z};
+  const float oc2 = vdot(oc, oc), b = vdot(oc, d), r2 = c4.w * c4.w;
+  const float q = oc2 - b * b * invDD; // squared distance of the centre from the line
+  return q <= r2 * 1.001f + 2e-6f * oc2 && !(b < 0.f && oc2 > r2 * 1.01f + 1e-12f);
+}
+
 // geometry, per-lane: every lane walks its own path (incoherent rays).  Divergent lanes
 // make every node fetch 64 separate requests, so this walk reads the 16-byte nodes:
 // one dwordx4 per visit.  The slab test runs in the quantised frame (ray transformed
@@ -382,6 +395,7 @@ __device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, 
                    (o.z - p.qbase[2]) * p.qscale[2] * inv.z};
   if (!part)
     node = VR_END;
+  const float invDD = 1.0f / vdot(d, d);
   // Two alternating phases ("while-while"): a lane SEARCHES for leaves whose box it hits.
   // The first such leaf is only remembered (`pend`) and the lane searches on
   // (speculatively: it may visit nodes the pending leaf's hit would have culled); at a
@@ -446,9 +460,11 @@ __device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, 
         float t;
         if (GEO == 0) {
           const float4 c4 = prims[2 * q];
-          const float4 n4 = prims[2 * q + 1];
-          const bool ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
-          hit_update(h, on && ok, t, __float_as_uint(n4.w), q);
+          if (on && disc_may_hit(o, d, invDD, c4)) { // (exec-masked: lanes that fail fetch nothing more)
+            const float4 n4 = prims[2 * q + 1];
+            const bool ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
+            hit_update(h, ok, t, __float_as_uint(n4.w), q);
+          }
         } else {
           const float4 a = prims[4 * q], b = prims[4 * q + 1], c = prims[4 * q + 2], e = prims[4 * q + 3];
           const bool ok =
