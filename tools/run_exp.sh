@@ -1,16 +1,13 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-for C in "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_TCC_READ_REQ_LATENCY_sum" "TA_TA_BUSY_sum TA_BUSY_avr TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum"; do
-N=$(echo $C | tr ' ' '_' | cut -c1-30)
-rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/expc/$N -- python3 $R/tools/case_bench.py trench3d 0.1 4000 1 > /dev/null 2>&1
-echo "pmc $C rc=$?"
-done
-python3 - <<PY
-import csv,glob,collections
-agg=collections.defaultdict(float)
-for f in glob.glob("$R/gpurun_out/expc/**/*counter_collection.csv",recursive=True):
-    for r in csv.DictReader(open(f)):
-        if "trace_kernel" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]]+=float(r["Counter_Value"])
-for c,v in sorted(agg.items()): print("%-36s %.4g"%(c,v))
-PY
+cd $GRAFT_REPO_ROOT
+for i in 1 2; do
+for lib in libviennaray_amd.so libviennaray_amd_exp.so; do
+echo "== $lib"
+export VR_LIB_PATH=$GRAFT_REPO_ROOT/viennaray_amd/$lib
+python3 tools/case_bench.py trench3d 0.1 4000 2 | tail -1
+python3 tools/case_bench.py C5p 2 | tail -1
+python3 tools/case_bench.py trench3d 1.0 10000 2 | tail -1
+python3 bench.py --steps 5 --warmup 1 --cpu-rays 0 --no-secondary --no-parity --sticking 0.1 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('C2 s=0.1', d['value'], 'Mrays/s  trace', d['trace_kernel_ms'])"
+done; done
