@@ -34,6 +34,9 @@ hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st
 hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, unsigned replicas,
                               const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, hipStream_t s);
 
+// cell grid (vr_grid.hip): count pass; after the scan of cellStart: fill + finish
+hipError_t launch_grid_count(const GridParams &g, hipStream_t st);
+hipError_t launch_grid_fill(const GridParams &g, hipStream_t st);
 // 64-ary box tree for the packet query (vr_setup.hip)
 size_t wide_tree_entries(unsigned n);
 hipError_t launch_wide_tree(const SetupParams &s, unsigned *out3, hipStream_t st);
