@@ -169,6 +169,61 @@ def test_closest_hit_matches_oracle(geom):
             assert prim[i] == h["primID"] and tt[i] == np.float32(h["t"]), (i, prim[i], h)
 
 
+@pytest.mark.parametrize("geom", ["sphere", "trench3d", "trench2d", "mesh"])
+def test_ordered_walk_equals_escape_link_walk(geom, monkeypatch):
+    """The trace kernels' ordered per-lane walk (pair nodes, near child first, LDS stack) and the escape-link
+    walk it replaced find the same closest hit, bit for bit, on primary-like rays and on rays that start ON the
+    surface (bounces): the closest-hit rule does not depend on the traversal order."""
+    rng = np.random.default_rng(11)
+    if geom == "mesh":
+        gd, v, tri = trench_mesh()
+        t = vr.TraceTriangle(3)
+        t.setGeometry(v, tri, gd)
+        lo, hi, D = v.min(0), v.max(0), 3
+    else:
+        gd, p, n = {"sphere": sphere3d, "trench3d": trench3d, "trench2d": trench2d}[geom]()
+        D = 2 if geom == "trench2d" else 3
+        t = vr.TraceDisk(D)
+        t.setGeometry(p, n, gd)
+        lo, hi = p.min(0), p.max(0)
+        if D == 2:
+            t.setSourceDirection(TD.POS_Y)
+    t.setParticleType(vr.DiffuseParticle(0.1, "f"))
+    up = 1 if D == 2 else 2
+    nr = 200_000
+    o = rng.uniform(lo, hi, size=(nr, 3)).astype(np.float32)
+    o[:, up] = hi[up] + gd
+    d = rng.normal(size=(nr, 3)) * 0.3
+    d[:, up] = -1.0
+    if D == 2:
+        o[:, 2] = 0
+        d[:, 2] = 0
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+
+    def both(o, d):
+        monkeypatch.setenv("VR_DEBUG_WALK", "0")
+        g0, p0, t0 = t.debugIntersect(o, d)
+        monkeypatch.setenv("VR_DEBUG_WALK", "1")
+        g1, p1, t1 = t.debugIntersect(o, d)
+        assert np.array_equal(g0, g1)
+        m = g0 >= 0
+        assert np.array_equal(p0[m], p1[m]) and np.array_equal(t0[m].view(np.uint32), t1[m].view(np.uint32))
+        return g0, t0
+
+    g, tt = both(o, d)
+    m = g == 1
+    assert m.sum() > nr // 4
+    o2 = (o[m] + d[m] * tt[m, None]).astype(np.float32)
+    d2 = rng.normal(size=o2.shape)
+    if D == 2:
+        d2[:, 2] = 0
+    d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)
+    both(o2, d2)
+    d3 = np.zeros_like(o2)
+    d3[:, 0] = rng.choice([-1.0, 1.0], size=len(o2))  # axis-parallel, zero components (inverse = +-1e30)
+    both(o2, d3.astype(np.float32))
+
+
 # ---------------------------------------------------------------------------
 def test_rng_seed_config_bit_exact():
     """tests/rngSeed/rngSeed.cpp geometry: 21x21 plane, sticking 1, 10 rays/point.

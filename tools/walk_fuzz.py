@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Closest hit through the cell grid against the BVH walk on millions of rays of the kinds the tracer
-produces (primary rays, bounced rays starting ON the surface, specular and axis-parallel directions).
-usage: tools/grid_fuzz.py <mesh|trench3d|trench2d|sphere> [rays]"""
+"""Closest hit of the ordered (pair-node, stack) walk against the escape-link walk on millions of rays of the
+kinds the tracer produces (primary rays, bounced rays starting ON the surface, mirrored and axis-parallel
+directions, origins on lattice points).   usage: tools/walk_fuzz.py <mesh|trench3d|trench2d|sphere> [rays]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ import viennaray_amd as vr
 from helpers import trench3d, trench2d, trench_mesh, sphere3d
 
 case = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 4_000_000
-os.environ["VR_DEBUG_GRID"] = "1"
+
 D = 3
 if case == "mesh":
     gd, v, tri = trench_mesh(); t = vr.TraceTriangle(3); t.setGeometry(v, tri, gd); lo, hi = v.min(0), v.max(0)
@@ -24,12 +24,12 @@ rng = np.random.default_rng(7)
 up = 1 if D == 2 else 2
 
 def both(o, d, tag):
-    os.environ["VR_DEBUG_GRID"] = "0"; g0, p0, t0 = t.debugIntersect(o, d)
-    os.environ["VR_DEBUG_GRID"] = "1"; g1, p1, t1 = t.debugIntersect(o, d)
+    os.environ["VR_DEBUG_WALK"] = "0"; g0, p0, t0 = t.debugIntersect(o, d)
+    os.environ["VR_DEBUG_WALK"] = "1"; g1, p1, t1 = t.debugIntersect(o, d)
     bad = np.nonzero((g0 != g1) | ((g0 >= 0) & ((p0 != p1) | (t0 != t1))))[0]
     print(f"{case} {tag}: rays {len(o)} geometry hits {int((g0 == 1).sum())} mismatches {len(bad)}")
     for i in bad[:8]:
-        print("   ray", i, "o", o[i].tolist(), "d", d[i].tolist(), "bvh", (g0[i], p0[i], t0[i]), "grid", (g1[i], p1[i], t1[i]))
+        print("   ray", i, "o", o[i].tolist(), "d", d[i].tolist(), "escape-link walk", (g0[i], p0[i], t0[i]), "ordered walk", (g1[i], p1[i], t1[i]))
     return g0, p0, t0
 
 o = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32); o[:, up] = hi[up] + gd

@@ -120,7 +120,8 @@ struct vr_context {
   // device-side setup (vr_setup.hip)
   DevBuf<float> dDisk4, dNormal3, dPoints3, dVerts, dBox, dSBox, dNodeBox;
   DevBuf<uint32_t> dTris, dBounds, dValsA, dValsB, dSortTable, dRangeLo, dRangeHi, dChildL, dChildR, dParentInt,
-      dParentLeaf, dArrive, dOrder, dSubSize, dQNodes;
+      dParentLeaf, dArrive, dOrder, dSubSize, dQNodes, dPNodes, dWalkStack;
+  size_t walkStackWaves = 0;
   DevBuf<float> dNodesPre, dWide;
   uint32_t wideRoot[3] = {0, 0, 0};  // 64-ary tree: root's first child, count | flag, primitive base
   bool haveWide = false;
@@ -137,14 +138,6 @@ struct vr_context {
   int bvhRefits = 0;             // 1 if the last build had to be re-fitted with agent-scope fences
   float builtOrderSign = 0.f;
   DevBuf<unsigned long long> dKeysA, dKeysB;
-  // cell grid (vr_grid.hpp): built on demand for the kernels that walk per lane
-  DevBuf<uint32_t> dCellStart, dCellFill, dCellHdr, dGridStats;
-  DevBuf<float> dCellRecs;
-  DevBuf<unsigned long long> dBrickMask;
-  bool gridBuilt = false, gridUsable = false; // built for the resident geometry / fit for use
-  uint32_t gridDim[3] = {0, 0, 0}, brickDim[3] = {0, 0, 0};
-  float gridLo[3] = {0, 0, 0}, gridH = 0.f;
-  uint32_t gridMaxList = 0, gridOccupied = 0, gridRecords = 0;
   bool hostOrderValid = false;   // c->bvh.order mirrors dOrder
   bool hostNeighborsValid = false;
   // ray stream (one batch)
@@ -506,104 +499,9 @@ static int quantize_scene(vr_context *c, const float *preNodes, const float *roo
     c->qbase[k] = ext > 0.f ? lo[k] - 2.0f / c->qscale[k] : lo[k];
   }
   VR_HIP(c, c->dQNodes.ensure((size_t)c->numNodes * 4));
-  VR_HIP(c, launch_quantize_nodes(preNodes, c->numNodes, c->qbase, c->qscale, c->dQNodes.p, c->stream));
+  VR_HIP(c, c->dPNodes.ensure((size_t)std::max<uint32_t>(c->numNodes, 1u) * 8));
+  VR_HIP(c, launch_quantize_nodes(preNodes, c->numNodes, c->qbase, c->qscale, c->dQNodes.p, c->dPNodes.p, c->stream));
   VR_HIP(c, hipStreamSynchronize(c->stream));
-  return VR_OK;
-}
-
-// Cell grid over the resident scene (vr_grid.hpp, vr_grid.hip).  Cell edge: a small multiple of the
-// primitive size, grown until the occupancy words fit the LDS budget of a block (VR_GRID_BRICKS);
-// a scene whose cells would then list more than 63 primitives keeps the BVH walk.
-static int build_grid(vr_context *c) {
-  c->gridBuilt = true;
-  c->gridUsable = false;
-  const HostGeometry &g = c->geo;
-  if (!c->haveSetup || g.numPrims == 0)
-    return VR_OK; // (host-built validation scenes: BVH walk only)
-  float base = g.geo == 0 ? 2.3f * g.diskRadius : 2.0f * g.gridDelta;
-  if (const char *e = std::getenv("VR_GRID_H"))
-    base = (float)std::atof(e) * (g.geo == 0 ? g.diskRadius : g.gridDelta);
-  if (!(base > 0.f))
-    return VR_OK;
-  float scale = 1e-3f, ext[3];
-  for (int k = 0; k < 3; ++k) {
-    scale = std::max(scale, std::max(std::fabs(c->sceneLo[k]), std::fabs(c->sceneHi[k])));
-    ext[k] = c->sceneHi[k] - c->sceneLo[k];
-  }
-  float H = base;
-  uint32_t dim[3], bdim[3];
-  for (int it = 0; it < 400; ++it, H *= 1.05f) {
-    uint64_t bricks = 1;
-    bool fits = true;
-    for (int k = 0; k < 3; ++k) {
-      const double cells = std::floor((double)ext[k] / H) + 2.0; // one cell of slack on the far side
-      fits = fits && cells <= 1020.0;
-      dim[k] = (uint32_t)((((uint64_t)cells + 3) / 4) * 4);
-      bdim[k] = dim[k] / 4;
-      bricks *= bdim[k];
-    }
-    if (fits && bricks <= VR_GRID_BRICKS)
-      break;
-    if (it == 399)
-      return VR_OK;
-  }
-  const size_t cells = (size_t)dim[0] * dim[1] * dim[2];
-  GridParams gp{};
-  gp.sbox = c->dSBox.p;
-  gp.prims = c->dPrims.p;
-  gp.n = g.numPrims;
-  gp.geo = g.geo;
-  for (int k = 0; k < 3; ++k) {
-    gp.lo[k] = c->sceneLo[k] - 0.5f * H; // (half a cell of slack on the near side)
-    gp.dim[k] = dim[k];
-    gp.bdim[k] = bdim[k];
-  }
-  gp.invH = 1.0f / H;
-  gp.pad = 2e-3f * H + 1e-5f * scale;
-  VR_HIP(c, c->dCellStart.ensure(cells + 1));
-  VR_HIP(c, c->dCellFill.ensure(cells));
-  VR_HIP(c, c->dCellHdr.ensure(cells));
-  VR_HIP(c, c->dBrickMask.ensure((size_t)bdim[0] * bdim[1] * bdim[2]));
-  VR_HIP(c, c->dGridStats.ensure(2));
-  VR_HIP(c, c->dScanTmp.ensure(2 * ((cells + 1) / 2048 + 4) + 64));
-  gp.cellStart = c->dCellStart.p;
-  gp.cellFill = c->dCellFill.p;
-  gp.cellHdr = c->dCellHdr.p;
-  gp.brickMask = c->dBrickMask.p;
-  gp.stats = c->dGridStats.p;
-  VR_HIP(c, hipMemsetAsync(gp.cellStart, 0, (cells + 1) * 4, c->stream));
-  VR_HIP(c, hipMemsetAsync(gp.cellFill, 0, cells * 4, c->stream));
-  VR_HIP(c, hipMemsetAsync(gp.stats, 0, 8, c->stream));
-  VR_HIP(c, launch_grid_count(gp, c->stream));
-  VR_HIP(c, launch_scan(gp.cellStart, (unsigned)(cells + 1), c->dScanTmp.p, c->stream));
-  uint32_t total = 0;
-  VR_HIP(c, hipMemcpyAsync(&total, gp.cellStart + cells, 4, hipMemcpyDeviceToHost, c->stream));
-  VR_HIP(c, hipStreamSynchronize(c->stream));
-  if (total >= (1u << 26))
-    return VR_OK;
-  VR_HIP(c, c->dCellRecs.ensure((size_t)std::max<uint32_t>(total, 1u) * (g.geo == 0 ? 8 : 16)));
-  gp.cellRecs = c->dCellRecs.p;
-  VR_HIP(c, launch_grid_fill(gp, c->stream));
-  uint32_t stats[2] = {0, 0};
-  VR_HIP(c, hipMemcpyAsync(stats, gp.stats, 8, hipMemcpyDeviceToHost, c->stream));
-  VR_HIP(c, hipStreamSynchronize(c->stream));
-  for (int k = 0; k < 3; ++k) {
-    c->gridDim[k] = dim[k];
-    c->brickDim[k] = bdim[k];
-    c->gridLo[k] = gp.lo[k];
-  }
-  c->gridH = H;
-  c->gridMaxList = stats[0];
-  c->gridOccupied = stats[1];
-  c->gridRecords = total;
-  uint32_t maxList = 63;
-  if (const char *e = std::getenv("VR_GRID_MAXLIST"))
-    maxList = (uint32_t)std::min(63, std::max(1, std::atoi(e)));
-  c->gridUsable = stats[0] <= maxList;
-  if (const char *e = std::getenv("VR_GRID_VERBOSE"))
-    if (std::atoi(e))
-      std::fprintf(stderr, "[vr] cell grid %ux%ux%u H=%g records=%u occupied=%u maxList=%u usable=%d\n", dim[0], dim[1],
-                   dim[2], (double)H, total, stats[1], stats[0], (int)c->gridUsable);
   return VR_OK;
 }
 
@@ -611,9 +509,6 @@ static int build_scene(vr_context *c) {
   HostGeometry &g = c->geo;
   const uint32_t N = g.numPrims;
   const bool disk = g.geo == 0;
-  c->gridBuilt = false;
-  c->gridUsable = false;
-  c->haveSetup = false;
   c->hostOrderValid = false;
   c->hostNeighborsValid = false;
   VR_HIP(c, c->dLeafOfOrig.ensure(N));
@@ -1064,25 +959,20 @@ int vr_apply_prepare(vr_context *c) {
     if (const char *e = std::getenv("VR_ABSORB_CARRY"))
       if (c->absorb)
         c->traceMode = std::atoi(e) ? 2 : 1;
-    // rounds that end in per-lane walks take them through the cell grid when the scene allows one
-    // (measured slower than the BVH walk on every fixture — DESIGN.md 7 — so only on request: VR_GRID=1)
-    bool wantGrid = false;
-    if (const char *e = std::getenv("VR_GRID"))
-      wantGrid = (c->traceMode == 0 || c->traceMode == 2) && std::atoi(e) != 0;
-    const char *dg = std::getenv("VR_DEBUG_GRID");
-    if ((wantGrid || (dg && std::atoi(dg))) && !c->gridBuilt) {
-      int r = build_grid(c);
-      if (r != VR_OK)
-        return r;
-    }
-    if (wantGrid && c->gridUsable)
-      c->traceMode = c->traceMode == 0 ? 4 : 5;
     int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->kernelParticle, c->traceMode));
     if (c->overlap && blocks > 4)
       blocks -= 2; // leave wave slots for the concurrently running generator / sorter
     if (const char *e = std::getenv("VR_TRACE_BLOCKS"))
       blocks = std::max(1, std::atoi(e));
     c->grid = (unsigned)c->numCUs * (unsigned)blocks;
+  }
+  // deep part of the per-lane walk's stack (entries beyond the LDS-resident ones), one slab per resident wave
+  {
+    const size_t waves = (size_t)std::max<unsigned>(c->grid, (unsigned)c->numCUs * 8u) * (VR_BLOCK / 64);
+    if (waves > c->walkStackWaves) {
+      VR_HIP(c, c->dWalkStack.ensure(waves * (size_t)VR_STACK_GLOBAL * 64u));
+      c->walkStackWaves = waves;
+    }
   }
   // tier-2 RNG slabs (312 x 64 words per resident wave): only a kernel that can draw more than
   // 156 numbers per ray touches them — the general trace kernel and the tilted-source generator
@@ -1100,6 +990,8 @@ int vr_apply_prepare(vr_context *c) {
 
   p.nodes = c->dNodes.p;
   p.qnodes = c->dQNodes.p;
+  p.pnodes = c->dPNodes.p;
+  p.walkStack = c->dWalkStack.p;
   p.numNodes = c->numNodes;
   for (int k = 0; k < 3; ++k) {
     p.qbase[k] = c->qbase[k];
@@ -1127,17 +1019,6 @@ int vr_apply_prepare(vr_context *c) {
     p.geoD = D;
     p.pqPad = 1e-5f * scale; // >> the rounding of the clip (1e-7 relative); the boxes carry their own 4e-6 pad
   }
-  p.cellHdr = c->gridUsable ? c->dCellHdr.p : nullptr;
-  p.cellRecs = c->dCellRecs.p;
-  p.brickMask = c->dBrickMask.p;
-  for (int k = 0; k < 3; ++k) {
-    p.gridDim[k] = c->gridDim[k];
-    p.brickDim[k] = c->brickDim[k];
-    p.gridLo[k] = c->gridLo[k];
-  }
-  p.numBricks = c->gridUsable ? c->brickDim[0] * c->brickDim[1] * c->brickDim[2] : 0u;
-  p.gridH = c->gridH;
-  p.gridInvH = c->gridH > 0.f ? 1.0f / c->gridH : 0.f;
   p.nbOff = c->dNbOff.p;
   p.nbIds = c->dNbIds.p;
   p.primSticking = dStick;
@@ -1354,28 +1235,41 @@ int vr_apply_finish(vr_context *c) {
     VR_HIP(c, hipMemcpy(dg, c->dCounters.p + 16, sizeof(dg), hipMemcpyDeviceToHost));
     static const char *names[16] = {"rounds", "walk steps", "leaf prim tests", "packet visits", "packet prim tests",
                                     "state machine", "neighbour iters", "reflect iters", "refill reps", "wall init",
-                                    "roulette", "credit", "pq attempts", "pq done", "-", "-"};
+                                    "roulette", "credit", "pq attempts", "pq done", "visits: no child hit", "visits: both hit"};
     for (int k = 0; k < 16; ++k)
       if (dg[2 * k])
         std::fprintf(stderr, "diag %-18s wave-iters %12llu  lane-iters %14llu  (%.1f lanes)\n", names[k], dg[2 * k],
                      dg[2 * k + 1], (double)dg[2 * k + 1] / (double)dg[2 * k]);
   }
 #endif
-  if (c->params.debugFlags & 256u) { // grid self-check of the trace kernel (vr_trace.hip)
+  {
+    // the walk's stack ran out (a tree deeper than SD + VR_STACK_GLOBAL levels of deferred children): the
+    // result would be wrong, so the apply fails
+    unsigned long long ovf = 0;
+    VR_HIP(c, hipMemcpy(&ovf, c->dCounters.p + 60, 8, hipMemcpyDeviceToHost));
+    if (ovf) {
+      c->launched = false;
+      c->prepared = false;
+      return fail(c, VR_E_STATE, "BVH traversal stack overflow (degenerate tree): result discarded");
+    }
+  }
+#ifdef VR_SELFCHECK
+  {
     unsigned long long sc[12];
     VR_HIP(c, hipMemcpy(sc, c->dCounters.p + 48, sizeof(sc), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[vr] grid self-check: %llu segments disagree with the BVH walk\n", sc[0]);
+    std::fprintf(stderr, "[vr] self-check: %llu segments disagree with the escape-link walk\n", sc[0]);
     if (sc[0]) {
       float v[8];
       for (int k = 0; k < 8; ++k) {
         const uint32_t u = (uint32_t)sc[2 + k];
         std::memcpy(&v[k], &u, 4);
       }
-      std::fprintf(stderr, "[vr]   first: o %.9g %.9g %.9g d %.9g %.9g %.9g grid t %.9g pos %u geom %d | bvh t %.9g pos %u geom %d\n",
+      std::fprintf(stderr, "[vr]   first: o %.9g %.9g %.9g d %.9g %.9g %.9g  t %.9g pos %u geom %d | ref t %.9g pos %u geom %d\n",
                    v[0], v[1], v[2], v[3], v[4], v[5], v[6], (unsigned)(sc[10] >> 32), (int)(sc[11] >> 32), v[7],
                    (unsigned)(sc[10] & 0xFFFFFFFFu), (int)(sc[11] & 0xFFFFFFFFu));
     }
   }
+#endif
   float ms = 0.f;
   VR_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   vr_trace_info &i = c->info;
@@ -1742,14 +1636,17 @@ int vr_debug_intersect(vr_context *c, const float *org, const float *dir, const 
   VR_HIP(c, hipMemcpy(dO.p, org, (size_t)n * 12, hipMemcpyHostToDevice));
   VR_HIP(c, hipMemcpy(dD.p, dir, (size_t)n * 12, hipMemcpyHostToDevice));
   VR_HIP(c, hipMemcpy(dT.p, tnear, (size_t)n * 4, hipMemcpyHostToDevice));
-  // VR_DEBUG_GRID=1: the closest hit through the cell grid (when the scene has one) instead of the BVH walk
-  TraceParams dp = c->params;
-  {
-    const char *dg = std::getenv("VR_DEBUG_GRID");
-    if (!(dg && std::atoi(dg)))
-      dp.cellHdr = nullptr;
+  // the ordered (pair-node, stack) walk of the trace kernels; VR_DEBUG_WALK=0: the escape-link walk it replaced
+  int ordered = 1;
+  if (const char *e = std::getenv("VR_DEBUG_WALK"))
+    ordered = std::atoi(e) != 0;
+  // (64-thread blocks running concurrently must not share a slab: at most walkStackWaves blocks per launch)
+  const uint32_t chunk = (uint32_t)std::max<size_t>(c->walkStackWaves, 1) * 64u;
+  for (uint32_t f0 = 0; f0 < n; f0 += chunk) {
+    const uint32_t m = std::min(chunk, n - f0);
+    VR_HIP(c, launch_debug_intersect(c->params, c->geo.geo, dO.p + 3 * (size_t)f0, dD.p + 3 * (size_t)f0, dT.p + f0, m,
+                                     dG.p + f0, dP.p + f0, dt.p + f0, ordered, (unsigned)std::max<size_t>(c->walkStackWaves, 1), c->stream));
   }
-  VR_HIP(c, launch_debug_intersect(dp, c->geo.geo, dO.p, dD.p, dT.p, n, dG.p, dP.p, dt.p, c->stream));
   VR_HIP(c, hipStreamSynchronize(c->stream));
   VR_HIP(c, hipMemcpy(geomID, dG.p, (size_t)n * 4, hipMemcpyDeviceToHost));
   VR_HIP(c, hipMemcpy(primID, dP.p, (size_t)n * 4, hipMemcpyDeviceToHost));

@@ -377,7 +377,10 @@ __device__ __forceinline__ bool disc_may_hit(const V3 &o, const V3 &d, float inv
   return q <= r2 * 1.001f + 2e-6f * oc2 && !(b < 0.f && oc2 > r2 * 1.01f + 1e-12f);
 }
 
-// geometry, per-lane: every lane walks its own path (incoherent rays).  Divergent lanes
+// geometry, per-lane, escape links: every lane walks its own path over the pre-order nodes.  Kept for the
+// absorbing flat-scene kernel (MODE 1), whose rounds are packets and which wants the single register of walk
+// state, as the reference walk of the -DVR_SELFCHECK build and of vr_debug_intersect (VR_DEBUG_WALK=0); the
+// kernels that walk a lot use pair_walk_lanes below.  Divergent lanes
 // make every node fetch 64 separate requests, so this walk reads the 16-byte nodes:
 // one dwordx4 per visit.  The slab test runs in the quantised frame (ray transformed
 // once per call; per-axis scaling leaves t unchanged); boxes were rounded outwards
@@ -479,12 +482,158 @@ __device__ __forceinline__ void bvh_walk_lanes(const TraceParams &p, bool part, 
   }
 }
 
-// one ray, whole walk (diagnostic entry points)
-template <int GEO>
-__device__ __forceinline__ void bvh_hit_lane(const TraceParams &p, const V3 &o, const V3 &d, float tnear, HitRec &h) {
-  unsigned node = 0u;
-  VR_DIAG_DECL
-  bvh_walk_lanes<GEO>(p, true, o, d, tnear, h, node, 1u VR_DIAG_PASS);
+// ---------------------------------------------------------------------------
+// geometry, per-lane, ORDERED: the walk of bounced rays.  bvh_walk_lanes follows the escape links of a
+// pre-order layout: one node (one 16-byte gather, one dependent cache access) per box test, and the
+// order of the children is fixed at build time (source side first) — right for primary rays, wrong for
+// half of the bounced ones, which then cannot be culled by a close hit.  Here a visit reads a PAIR node
+// (both children of an internal node, 32 bytes of one line), tests both boxes, descends into the NEARER
+// child and defers the other on a per-lane stack whose first SD entries live in LDS ([entry][lane]: conflict
+// free) and the (rare) rest in a per-wave global slab.  Half the dependent accesses per box test, and the
+// near-first order finds the closest hit early, so far subtrees fail `tEntry <= h.t` when they are popped.
+// The closest-hit rule makes the result independent of the order: bit-identical to bvh_walk_lanes.
+//   `node`: cursor — 0 = fresh (root pair), VR_END = finished, else a pair index or a leaf word.
+//   `sp`:   stack depth of the lane (the caller keeps it with `node` between rounds).
+// ---------------------------------------------------------------------------
+template <int SD>
+__device__ __forceinline__ void walk_push(unsigned *stackS, unsigned *stackG, unsigned long long *errFlag, unsigned &sp,
+                                          unsigned v) {
+  if (sp < (unsigned)SD)
+    stackS[sp * VR_BLOCK] = v;
+  else if (sp < (unsigned)SD + VR_STACK_GLOBAL)
+    stackG[(sp - (unsigned)SD) * 64u] = v;
+  else
+    *errFlag = 1ull; // deeper than any tree the builder emits: reported by vr_apply_finish, never silent
+  ++sp;
+}
+template <int SD> __device__ __forceinline__ unsigned walk_pop(const unsigned *stackS, const unsigned *stackG, unsigned &sp) {
+  --sp;
+  if (sp < (unsigned)SD)
+    return stackS[sp * VR_BLOCK];
+  return sp < (unsigned)SD + VR_STACK_GLOBAL ? stackG[(sp - (unsigned)SD) * 64u] : VR_END;
+}
+
+// stackS: this lane's column of the LDS stack (entry e at stackS[e * VR_BLOCK]); stackG: this lane's column of
+// the wave's global slab (entry e at stackG[e * 64])
+template <int GEO, int SD>
+__device__ __forceinline__ void pair_walk_lanes(const TraceParams &p, unsigned *stackS, unsigned *stackG, bool part,
+                                                const V3 &o, const V3 &d, float tnear, HitRec &h, unsigned &node,
+                                                unsigned &sp, unsigned minLanes VR_DIAG_ARGS) {
+  const uint4 *__restrict__ pnodes = reinterpret_cast<const uint4 *>(p.pnodes);
+  const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
+  const V3 inv = safe_inverse(V3{d.x * p.qscale[0], d.y * p.qscale[1], d.z * p.qscale[2]});
+  const V3 oi = V3{(o.x - p.qbase[0]) * p.qscale[0] * inv.x, (o.y - p.qbase[1]) * p.qscale[1] * inv.y,
+                   (o.z - p.qbase[2]) * p.qscale[2] * inv.z};
+  if (!part)
+    node = VR_END;
+  sp = node == 0u ? 0u : sp;
+  const float invDD = 1.0f / vdot(d, d);
+  unsigned long long *const errFlag = p.counters + 60;
+  unsigned pend = 0u; // pending leaf word or 0
+  for (;;) {
+    bool parked = false; // at a second leaf while the first is still pending
+    for (;;) {
+      const unsigned long long sm = ballot64(node != VR_END && !parked);
+      if (!sm)
+        break;
+      const unsigned long long km = ballot64(parked);
+      if (100u * (unsigned)__popcll(km) >= p.walkPark * (unsigned)__popcll(km | sm))
+        break;
+#pragma unroll
+      for (int rep = 0; rep < 2; ++rep) {
+        const bool live = node != VR_END && !parked;
+        const bool atLeaf = live && (node & VR_LEAF) != 0u; // (a deferred child that is a leaf, popped)
+        const bool visit = live && !atLeaf;
+#ifdef VR_DIAG
+        if (visit) {
+          DIAG(1);
+        }
+#endif
+        const size_t idx = visit ? (size_t)node : 0u;
+        const uint4 a = pnodes[2 * idx], b = pnodes[2 * idx + 1];
+        bool hit0, hit1;
+        float e0, e1;
+        {
+          const float lx = (float)(a.x & 0xFFFFu), ly = (float)(a.x >> 16), lz = (float)(a.y & 0xFFFFu);
+          const float hx = (float)(a.y >> 16), hy = (float)(a.z & 0xFFFFu), hz = (float)(a.z >> 16);
+          const float tx0 = __builtin_fmaf(lx, inv.x, -oi.x), tx1 = __builtin_fmaf(hx, inv.x, -oi.x);
+          const float ty0 = __builtin_fmaf(ly, inv.y, -oi.y), ty1 = __builtin_fmaf(hy, inv.y, -oi.y);
+          const float tz0 = __builtin_fmaf(lz, inv.z, -oi.z), tz1 = __builtin_fmaf(hz, inv.z, -oi.z);
+          e0 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
+          const float x0 = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+          hit0 = e0 <= x0 && e0 <= h.t;
+        }
+        {
+          const float lx = (float)(b.x & 0xFFFFu), ly = (float)(b.x >> 16), lz = (float)(b.y & 0xFFFFu);
+          const float hx = (float)(b.y >> 16), hy = (float)(b.z & 0xFFFFu), hz = (float)(b.z >> 16);
+          const float tx0 = __builtin_fmaf(lx, inv.x, -oi.x), tx1 = __builtin_fmaf(hx, inv.x, -oi.x);
+          const float ty0 = __builtin_fmaf(ly, inv.y, -oi.y), ty1 = __builtin_fmaf(hy, inv.y, -oi.y);
+          const float tz0 = __builtin_fmaf(lz, inv.z, -oi.z), tz1 = __builtin_fmaf(hz, inv.z, -oi.z);
+          e1 = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
+          const float x1 = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+          hit1 = e1 <= x1 && e1 <= h.t;
+        }
+        const bool both = hit0 && hit1, any = hit0 || hit1;
+#ifdef VR_DIAG
+        if (visit && !any) {
+          DIAG(14);
+        }
+        if (visit && both) {
+          DIAG(15);
+        }
+#endif
+        const bool second = hit1 && (!hit0 || e1 < e0); // child 1 is the nearer one
+        const unsigned nearL = second ? b.w : a.w, farL = second ? a.w : b.w;
+        // a leaf goes into the pending slot when that is free; with the slot taken the lane parks on it
+        const bool nearLeaf = (nearL & VR_LEAF) != 0u;
+        const bool takeNear = visit && any && nearLeaf && pend == 0u;
+        const bool takeSelf = atLeaf && pend == 0u;
+        const bool park = atLeaf && pend != 0u;
+        pend = takeNear ? nearL : (takeSelf ? node : pend);
+        // where next: the nearer child, or — nothing (more) to enter here — the far child / the stack
+        const bool descend = visit && any && !takeNear;
+        const bool toFar = takeNear && both;
+        const bool pop = (visit && !any) || (takeNear && !both) || takeSelf;
+        if (descend && both)
+          walk_push<SD>(stackS, stackG, errFlag, sp, farL);
+        unsigned nxt = descend ? nearL : (toFar ? farL : node);
+        if (pop)
+          nxt = sp ? walk_pop<SD>(stackS, stackG, sp) : VR_END;
+        node = nxt;
+        parked = parked || park;
+      }
+    }
+    if (ballot64(pend != 0u)) {
+      const unsigned first = pend & VR_LEAF_FIRST_MASK;
+      const unsigned cnt = pend ? (pend >> 27) & 15u : 0u;
+      for (unsigned i = 0; ballot64(i < cnt); ++i) {
+        const bool on = i < cnt;
+#ifdef VR_DIAG
+        if (on) {
+          DIAG(2);
+        }
+#endif
+        const unsigned q = on ? first + i : 0u;
+        float t;
+        if (GEO == 0) {
+          const float4 c4 = prims[2 * q];
+          if (on && disc_may_hit(o, d, invDD, c4)) {
+            const float4 n4 = prims[2 * q + 1];
+            const bool ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
+            hit_update(h, ok, t, __float_as_uint(n4.w), q);
+          }
+        } else {
+          const float4 a = prims[4 * q], b = prims[4 * q + 1], c = prims[4 * q + 2], e = prims[4 * q + 3];
+          const bool ok =
+              hit_tri(o, d, tnear, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(e.x, e.y, e.z), t);
+          hit_update(h, on && ok, t, __float_as_uint(a.w), q);
+        }
+      }
+      pend = 0u;
+    }
+    if ((unsigned)__popcll(ballot64(node != VR_END)) < minLanes)
+      break;
+  }
 }
 
 // geometry, wave-uniform ("packet"): the 64 rays of a wavefront that were sorted
@@ -808,14 +957,6 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
     }
   }
   return true;
-}
-
-template <int GEO>
-__device__ __forceinline__ void closest_hit(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
-                                            const V3 &d, float tnear, HitRec &h) {
-  hit_clear(h);
-  bvh_hit_lane<GEO>(p, o, d, tnear, h);
-  hit_walls(p, wallS, o, d, tnear, h);
 }
 
 // rayTraceKernel.hpp:462-507 (neighbour disk test)

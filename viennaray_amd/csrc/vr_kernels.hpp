@@ -14,8 +14,8 @@ hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int 
 // resident 256-thread blocks per CU of the trace kernel instantiation (occupancy API)
 int trace_blocks_per_cu(int D, int geo, int particle, int mode);
 hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *org, const float *dir,
-                                  const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t,
-                                  hipStream_t s);
+                                  const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t, int ordered,
+                                  unsigned walkStackWaves, hipStream_t s);
 hipError_t launch_debug_process_hit(const TraceParams &p, int D, const float *org, const float *dir, const float *tfar,
                                     const unsigned *prim, unsigned n, float *outOrg, float *outDir, int *outReflect,
                                     hipStream_t s);
@@ -29,14 +29,11 @@ hipError_t launch_smooth_flux(const float *fluxIn, float *fluxOut, const float *
                               const uint32_t *nbIds, const uint32_t *order, const uint32_t *leafOfOrig, unsigned n,
                               unsigned *overflow, hipStream_t st);
 hipError_t launch_quantize_nodes(const float *nodes, unsigned numNodes, const float *base3, const float *scale3,
-                                 uint32_t *qnodes, hipStream_t st);
+                                 uint32_t *qnodes, uint32_t *pnodes, hipStream_t st);
 hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st);
 hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, unsigned replicas,
                               const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, hipStream_t s);
 
-// cell grid (vr_grid.hip): count pass; after the scan of cellStart: fill + finish
-hipError_t launch_grid_count(const GridParams &g, hipStream_t st);
-hipError_t launch_grid_fill(const GridParams &g, hipStream_t st);
 // 64-ary box tree for the packet query (vr_setup.hip)
 size_t wide_tree_entries(unsigned n);
 hipError_t launch_wide_tree(const SetupParams &s, unsigned *out3, hipStream_t st);

@@ -449,6 +449,31 @@ __global__ void quantize_nodes_kernel(const float4 *nodes, unsigned numNodes, fl
   qnodes[i] = make_uint4(ql[0] | (ql[1] << 16), ql[2] | (qh[0] << 16), qh[1] | (qh[2] << 16), w);
 }
 
+// PAIR nodes for the ordered per-lane walk (vr_device.hpp: pair_walk_lanes): entry i (i = pre-order index of
+// an internal node) holds BOTH children — {box(c0), link(c0)} {box(c1), link(c1)}, 32 bytes in one cache
+// line — so one visit decides both, descends into the nearer one and defers the other.
+//   link: leaf -> its leaf word (VR_LEAF | cnt << 27 | first), internal -> its pre-order index
+// c0 = i + 1, c1 = the node after c0's subtree.  A scene that is one leaf gets the pair {that leaf, nothing}.
+__global__ void pair_nodes_kernel(const uint4 *qnodes, unsigned numNodes, uint4 *pnodes) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= numNodes)
+    return;
+  const uint4 me = qnodes[i];
+  if (me.w & VR_LEAF) {
+    if (i == 0u) { // the whole scene is one leaf
+      pnodes[0] = me;
+      pnodes[1] = make_uint4(0xFFFFFFFFu, 0x0000FFFFu, 0u, VR_LEAF); // lo = 65535 > hi = 0: never hit; empty leaf
+    }
+    return;
+  }
+  const unsigned c0 = i + 1u;
+  const uint4 a = qnodes[c0];
+  const unsigned c1 = (a.w & VR_LEAF) ? c0 + 1u : a.w;
+  const uint4 b = qnodes[c1];
+  pnodes[2 * (size_t)i] = make_uint4(a.x, a.y, a.z, (a.w & VR_LEAF) ? a.w : c0);
+  pnodes[2 * (size_t)i + 1] = make_uint4(b.x, b.y, b.z, (b.w & VR_LEAF) ? b.w : c1);
+}
+
 // sorted boxes, leafOfOrig, primitive records in leaf order
 __global__ void pack_kernel(SetupParams s) {
   const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -857,12 +882,14 @@ hipError_t launch_wide_tree(const SetupParams &s, unsigned *out3, hipStream_t st
 }
 
 hipError_t launch_quantize_nodes(const float *nodes, unsigned numNodes, const float *base3, const float *scale3,
-                                 uint32_t *qnodes, hipStream_t st) {
+                                 uint32_t *qnodes, uint32_t *pnodes, hipStream_t st) {
   if (numNodes == 0)
     return hipSuccess;
   hipLaunchKernelGGL(quantize_nodes_kernel, dim3((numNodes + 255) / 256), dim3(256), 0, st,
                      reinterpret_cast<const float4 *>(nodes), numNodes, base3[0], base3[1], base3[2], scale3[0],
                      scale3[1], scale3[2], reinterpret_cast<uint4 *>(qnodes));
+  hipLaunchKernelGGL(pair_nodes_kernel, dim3((numNodes + 255) / 256), dim3(256), 0, st,
+                     reinterpret_cast<const uint4 *>(qnodes), numNodes, reinterpret_cast<uint4 *>(pnodes));
   return hipGetLastError();
 }
 

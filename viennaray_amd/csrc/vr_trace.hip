@@ -25,7 +25,6 @@
 #include <type_traits>
 
 #include "vr_device.hpp"
-#include "vr_grid.hpp"
 #include "vr_kernels.hpp"
 #include "vr_particles.hpp"
 
@@ -368,13 +367,10 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 // MODE 0: general kernel.  MODE 1: absorbing, flat scene (packets carry the load).  MODE 2:
 // absorbing, structured scene (most rounds end in per-lane walks): straggler carry-over on.
 // MODE 3: general kernel for a flat scene: like 0, with the packet query's wave-uniform crediting.
-// MODE 4 / 5: MODE 0 / 2 with the per-lane rounds on the CELL GRID (vr_grid.hpp) instead of the BVH walk.
-template <int D, int GEO, int PARTICLE, int MODE_>
+template <int D, int GEO, int PARTICLE, int MODE>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
-__attribute__((amdgpu_waves_per_eu(MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : 6), MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : 6)))) void
+__attribute__((amdgpu_waves_per_eu(MODE == 1 ? 8 : (MODE == 2 ? 7 : 6), MODE == 1 ? 8 : (MODE == 2 ? 7 : 6)))) void
 trace_kernel(const TraceParams p) {
-  constexpr bool GRID = MODE_ >= 4;
-  constexpr int MODE = MODE_ == 4 ? 0 : (MODE_ == 5 ? 2 : MODE_);
   constexpr bool ABSORB = MODE == 1 || MODE == 2;
   // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
   // extended kernel — particle kind, data labels, WDIST crediting and mean-free-path scattering
@@ -397,7 +393,11 @@ trace_kernel(const TraceParams p) {
   // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
   __shared__ unsigned cntS[8 * VR_BLOCK];
   __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier / candidate lists
-  __shared__ unsigned long long brickS[GRID ? VR_GRID_BRICKS : 1]; // cell grid: occupancy word per 4x4x4-cell brick
+  // per-lane stack of the ordered walk, [entry][lane]; the absorbing flat-scene kernel walks rarely and keeps its
+  // 8 waves per SIMD with a short LDS part (deeper entries: global slab)
+  constexpr bool ORDERED = MODE != 1; // (MODE 1 walks rarely: it keeps the escape-link walk, one register of state)
+  constexpr int SD = 12;
+  __shared__ unsigned stackS[ORDERED ? SD * VR_BLOCK : 1];
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
@@ -406,9 +406,6 @@ trace_kernel(const TraceParams p) {
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     cntS[k * VR_BLOCK + tid] = 0u;
-  if (GRID)
-    for (unsigned k = tid; k < p.numBricks; k += VR_BLOCK)
-      brickS[k] = p.brickMask[k];
   __syncthreads();
   unsigned *const cnt = cntS + tid; // counter k of this lane: cnt[k * VR_BLOCK]
   enum { K_TRACES = 0, K_NONGEO, K_GEO, K_BOUNDARY, K_REFL, K_TERM, K_TIER2, K_PARTICLE };
@@ -429,7 +426,9 @@ trace_kernel(const TraceParams p) {
   unsigned numReflections = 0, boundaryHits = 0;
   bool hitFromBack = false;
   bool start = false; // this lane begins a new trace segment in this round
-  unsigned node = VR_END; // cursor of the lane's BVH walk (< numNodes while under way)
+  unsigned node = VR_END; // cursor of the lane's BVH walk (VR_END: none under way)
+  unsigned sp = 0u;       // ... and the depth of its stack
+  unsigned *const stackG = p.walkStack + (size_t)gwave * (VR_STACK_GLOBAL * 64u) + lane;
   HitRec h;               // closest hit so far of the lane's current segment
   h.t = 0.f;
   h.geom = -1;
@@ -581,20 +580,20 @@ trace_kernel(const TraceParams p) {
       --packetSkip;
     }
     if (!packetDone) {
-      const unsigned walking = (unsigned)__popcll(ballot64(active && (GRID ? grid_walking(node) : node < p.numNodes)));
+      const unsigned walking = (unsigned)__popcll(ballot64(active && (ORDERED ? node != VR_END : node < p.numNodes)));
       const unsigned minLanes = (!CARRY || exhausted || walking <= p.walkExit) ? 1u : p.walkExit;
-      if (GRID)
-        grid_walk_lanes<GEO>(p, brickS, active, org, dir, tnear, h, node, minLanes VR_DIAG_PASS);
+      if (ORDERED)
+        pair_walk_lanes<GEO, SD>(p, stackS + tid, stackG, active, org, dir, tnear, h, node, sp, minLanes VR_DIAG_PASS);
       else
         bvh_walk_lanes<GEO>(p, active, org, dir, tnear, h, node, minLanes VR_DIAG_PASS);
     }
-    const bool fin = active && (GRID ? !grid_walking(node) : node >= p.numNodes); // this lane's geometry walk is complete
-    if (GRID && (p.debugFlags & 256u)) {
-      // self-check (VR_DEBUG_FLAGS=256): every finished segment again with the BVH walk; disagreements are
-      // counted in counters[48] and the first one is kept in counters[50..]
+    const bool fin = active && (ORDERED ? node == VR_END : node >= p.numNodes); // this lane's geometry walk is complete
+#ifdef VR_SELFCHECK
+    { // -DVR_SELFCHECK build: every finished segment again with the escape-link walk; disagreements are
+      // counted in counters[48], the first one is kept in counters[50..]
       HitRec hb;
       hit_clear(hb);
-      unsigned nb = 0u;
+      unsigned nb = fin ? 0u : VR_END;
       bvh_walk_lanes<GEO>(p, fin, org, dir, tnear, hb, nb, 1u VR_DIAG_PASS);
       if (fin && (hb.geom != h.geom || (hb.geom == 1 && (hb.t != h.t || hb.pos != h.pos)))) {
         if (atomicAdd(&p.counters[48], 1ull) == 0ull) {
@@ -606,6 +605,7 @@ trace_kernel(const TraceParams p) {
         }
       }
     }
+#endif
     if (fin)
       hit_walls(p, wallS, org, dir, tnear, h); // boundary walls, where one can come before the hit
     // Merge same-disk credits of the wave into one atomic when that is likely to pay: rays of a
@@ -905,10 +905,6 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 1>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 2)
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 2>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
-  else if (mode == 5)
-    hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 5>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
-  else if (mode == 4)
-    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 4>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
     hipLaunchKernelGGL((trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else
@@ -938,7 +934,7 @@ template <class F> static auto dispatch_variant(int D, int geo, int particle, F 
 
 hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int mode, unsigned grid,
                         hipStream_t s) {
-  if (mode == 1 || mode == 2 || mode == 5)
+  if (mode == 1 || mode == 2)
     particle = 0; // the reflection model is unobservable: one instantiation serves all
   return dispatch_variant(D, geo, particle, [&](auto d, auto g, auto pt) {
     return launch_trace_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(p, mode, grid, s);
@@ -952,10 +948,6 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode) {
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 1>, VR_BLOCK, 0);
   else if (mode == 2)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 2>, VR_BLOCK, 0);
-  else if (mode == 5)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 5>, VR_BLOCK, 0);
-  else if (mode == 4)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 4>, VR_BLOCK, 0);
   else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>, VR_BLOCK, 0);
   else
@@ -964,7 +956,7 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode) {
 }
 
 int trace_blocks_per_cu(int D, int geo, int particle, int mode) {
-  if (mode == 1 || mode == 2 || mode == 5)
+  if (mode == 1 || mode == 2)
     particle = 0;
   return dispatch_variant(D, geo, particle, [&](auto d, auto g, auto pt) {
     return occ_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(mode);
@@ -972,54 +964,50 @@ int trace_blocks_per_cu(int D, int geo, int particle, int mode) {
 }
 
 // ---- diagnostics -----------------------------------------------------------
-template <int GEO, bool GRID>
-__global__ void debug_intersect_kernel(const TraceParams p, const float *org, const float *dir,
-                                       const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t) {
+template <int GEO>
+__global__ void debug_intersect_kernel(const TraceParams p, const float *org, const float *dir, const float *tnear,
+                                       unsigned n, int *geomID, unsigned *primID, float *t, int ordered,
+                                       unsigned walkStackWaves) {
   __shared__ float wallS[96];
-  __shared__ unsigned long long brickS[GRID ? VR_GRID_BRICKS : 1];
+  __shared__ unsigned stackS[12 * VR_BLOCK]; // (64-thread blocks: lane columns 0..63 of the [entry][VR_BLOCK] layout)
   for (unsigned k = threadIdx.x; k < 96; k += blockDim.x)
     wallS[k] = p.wallTable[k];
-  if (GRID)
-    for (unsigned k = threadIdx.x; k < p.numBricks; k += blockDim.x)
-      brickS[k] = p.brickMask[k];
   __syncthreads();
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  // (the walk votes wave-wide: every lane of the block takes part in the call)
+  const unsigned j = i < n ? i : 0u;
+  const V3 o = mk(org[3 * j], org[3 * j + 1], org[3 * j + 2]), d = mk(dir[3 * j], dir[3 * j + 1], dir[3 * j + 2]);
   HitRec h;
-  if (GRID) { // (the walk votes wave-wide: every lane of the block takes part in the call)
-    const unsigned j = i < n ? i : 0u;
-    const V3 o = mk(org[3 * j], org[3 * j + 1], org[3 * j + 2]), d = mk(dir[3 * j], dir[3 * j + 1], dir[3 * j + 2]);
-    hit_clear(h);
-    unsigned cur = 0u;
+  hit_clear(h);
+  if (ordered) {
+    unsigned node = 0u, sp = 0u;
     VR_DIAG_DECL
-    grid_walk_lanes<GEO>(p, brickS, i < n, o, d, tnear[j], h, cur, 1u VR_DIAG_PASS);
-    grid_fix_prim<GEO>(p, h);
-    hit_walls(p, wallS, o, d, tnear[j], h);
-    if (i >= n)
-      return;
+    // (diagnostic launches are small: the block index serves as the wave index of the global slab; the host bounds it)
+    pair_walk_lanes<GEO, 12>(p, stackS + threadIdx.x, p.walkStack + (size_t)(blockIdx.x % walkStackWaves) * (VR_STACK_GLOBAL * 64u) + threadIdx.x,
+                             i < n, o, d, tnear[j], h, node, sp, 1u VR_DIAG_PASS);
   } else {
-    if (i >= n)
-      return;
-    closest_hit<GEO>(p, wallS, mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]),
-                     mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), tnear[i], h);
+    unsigned node = 0u;
+    VR_DIAG_DECL
+    bvh_walk_lanes<GEO>(p, i < n, o, d, tnear[j], h, node, 1u VR_DIAG_PASS);
   }
+  hit_walls(p, wallS, o, d, tnear[j], h);
+  if (i >= n)
+    return;
   geomID[i] = h.geom;
   primID[i] = h.prim;
   t[i] = h.t;
 }
 
 hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *org, const float *dir,
-                                  const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t,
-                                  hipStream_t s) {
+                                  const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t, int ordered,
+                                  unsigned walkStackWaves, hipStream_t s) {
   const unsigned grid = (n + 63) / 64;
-  const bool useGrid = p.cellHdr != nullptr; // (the caller passes the grid only when it asks for the grid walk)
-  if (geo == 0 && useGrid)
-    hipLaunchKernelGGL((debug_intersect_kernel<0, true>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t);
-  else if (geo == 0)
-    hipLaunchKernelGGL((debug_intersect_kernel<0, false>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t);
-  else if (useGrid)
-    hipLaunchKernelGGL((debug_intersect_kernel<1, true>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t);
+  if (geo == 0)
+    hipLaunchKernelGGL((debug_intersect_kernel<0>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t,
+                       ordered, walkStackWaves);
   else
-    hipLaunchKernelGGL((debug_intersect_kernel<1, false>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t);
+    hipLaunchKernelGGL((debug_intersect_kernel<1>), dim3(grid), dim3(64), 0, s, p, org, dir, tnear, n, geomID, primID, t,
+                       ordered, walkStackWaves);
   return hipGetLastError();
 }
 

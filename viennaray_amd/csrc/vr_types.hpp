@@ -35,12 +35,16 @@ struct Tri {       // boundary wall triangle, Embree's precomputed form
 //   cursors of the streaming mt19937_64 (vr_device.hpp, struct Rng)
 constexpr unsigned VR_BIN_CAP = 64; // record slots per sort bin (one wavefront)
 constexpr int VR_BLOCK = 256;
-constexpr unsigned VR_GRID_BRICKS = 2048; // occupancy words of the cell grid a block stages in LDS (16 KB)
+// stack of the ordered per-lane walk: the first entries of a lane live in LDS ([entry][lane], 12 in
+// the kernels that walk a lot, 4 in the absorbing flat-scene kernel), deeper ones in a per-wave global slab
+constexpr unsigned VR_STACK_GLOBAL = 64;
 
 struct TraceParams {
   // geometry (device pointers)
   const float *nodes;         // float4 pairs (pre-order; packet traversal, scalar fetch)
   const uint32_t *qnodes;     // uint4 per node: 16-bit boxes + link (per-lane traversal)
+  const uint32_t *pnodes;     // uint4 pairs per internal node: both children, box + link each (ordered per-lane traversal)
+  uint32_t *walkStack;        // [waves][VR_STACK_GLOBAL][64]: stack entries beyond the LDS-resident ones
   uint32_t numNodes;
   float qbase[3], qscale[3];  // quantised coordinate = (x - qbase) * qscale
   const float *prims;         // float4 records
@@ -55,12 +59,6 @@ struct TraceParams {
   float pqPad;                         // outward padding of the packet's box (float rounding of the clip)
   float nbDist;                        // neighbourhood radius = 2 x disk radius (rayGeometryDisk.hpp:191-192)
   int32_t geoD;                        // dimension of the geometry (2: z does not enter the neighbour test's boxes)
-  // cell grid (vr_grid.hpp): cubic cells of edge gridH from gridLo; 4x4x4 cells = one brick
-  const uint32_t *cellHdr;               // [gridDim x*y*z]: first record << 6 | record count (<= 63)
-  const float *cellRecs;                 // records of the cell lists (disk 32 B: {c,r}{n,bits(leaf pos)}; triangle 64 B: .w of word 0 = leaf pos)
-  const unsigned long long *brickMask;   // [numBricks] bit (x&3) | (y&3)<<2 | (z&3)<<4: the cell holds records
-  uint32_t gridDim[3], brickDim[3], numBricks;
-  float gridLo[3], gridH, gridInvH;
   const uint32_t *nbOff;      // [numPrims+1], disk neighbourhood CSR (leaf order)
   const uint32_t *nbIds;      // leaf positions
   const float *primSticking;  // optional [numPrims] (leaf order) or nullptr
@@ -148,22 +146,6 @@ struct SetupParams {
   uint32_t *leafOfOrig, *order;
   uint32_t *nbOff, *nbIds;
   float *wide;            // 64-ary box tree (see TraceParams::wide), (n + n/64 + ...) x 8 floats
-};
-
-// device build of the cell grid (vr_grid.hip)
-struct GridParams {
-  const float *sbox;      // padded primitive boxes in leaf order (6 floats each)
-  const float *prims;     // primitive records in leaf order
-  uint32_t n;
-  int32_t geo;
-  float lo[3], invH, pad; // cell = floor((x - lo) * invH); boxes are widened by pad
-  uint32_t dim[3], bdim[3];
-  uint32_t *cellStart;    // [cells + 1] counts, then (scanned) first record of each cell
-  uint32_t *cellFill;     // [cells] fill cursors = final counts
-  uint32_t *cellHdr;      // [cells]
-  float *cellRecs;
-  unsigned long long *brickMask;
-  uint32_t *stats;        // [2]: largest list, occupied cells
 };
 
 // particle kinds of the device registry (include/viennaray_amd.h: VR_PARTICLE_*)
