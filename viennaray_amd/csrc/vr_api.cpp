@@ -526,7 +526,7 @@ static int build_scene(vr_context *c) {
     c->accStride = (N + 15u) & ~15u; // replicas start on 128-byte lines
     c->accPlanes = 0;                // (buffers are sized per data label in vr_apply_prepare)
   }
-  VR_HIP(c, c->dCounters.ensure(64));
+  VR_HIP(c, c->dCounters.ensure(80));
   VR_HIP(c, c->dNbOff.ensure((size_t)N + 1));
   const char *hb = std::getenv("VR_HOST_BUILD");
   if (hb && std::atoi(hb)) {
@@ -1199,7 +1199,7 @@ int vr_apply_launch(vr_context *c) {
   VR_HIP(c, hipSetDevice(c->device));
   const uint32_t N = c->geo.numPrims;
   VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)c->accStride * c->accReplicas * c->numData * 8, c->stream));
-  VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64 * 8, c->stream));
+  VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 80 * 8, c->stream));
   VR_HIP(c, hipEventRecord(c->ev0, c->stream));
   if (c->overlap)
     VR_HIP(c, hipStreamWaitEvent(c->stream2, c->ev0, 0));
@@ -1240,6 +1240,16 @@ int vr_apply_finish(vr_context *c) {
       if (dg[2 * k])
         std::fprintf(stderr, "diag %-18s wave-iters %12llu  lane-iters %14llu  (%.1f lanes)\n", names[k], dg[2 * k],
                      dg[2 * k + 1], (double)dg[2 * k + 1] / (double)dg[2 * k]);
+    unsigned long long ph[12];
+    VR_HIP(c, hipMemcpy(ph, c->dCounters.p + 64, sizeof(ph), hipMemcpyDeviceToHost));
+    static const char *pn[12] = {"refill", "packets", "walk: search", "walk: leaf tests", "walls", "state machine + credit",
+                                 "packet-query credit", "tail", "  (of state machine) neighbour loop", "  (of state machine) reflection + roulette", "  (of state machine) credit of the closest primitive", "  (of state machine) boundary hit"};
+    double tot = 0;
+    for (int k = 0; k < 8; ++k)
+      tot += (double)ph[k];
+    for (int k = 0; k < 12; ++k)
+      if (ph[k])
+        std::fprintf(stderr, "phase %-24s %5.1f %% of wave time\n", pn[k], 100.0 * (double)ph[k] / tot);
   }
 #endif
   {
@@ -1346,7 +1356,7 @@ int vr_apply_sharded(vr_context *c, int rank, int world, vr_allreduce_fn reduce,
       return r;
   } else {
     VR_HIP(c, hipMemsetAsync(c->fluxOut(), 0, (size_t)N * c->numData * 8, c->stream));
-    VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 64 * 8, c->stream));
+    VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 80 * 8, c->stream));
     VR_HIP(c, hipEventRecord(c->ev0, c->stream));
     VR_HIP(c, hipEventRecord(c->ev1, c->stream));
     c->numBatches = 0;

@@ -72,11 +72,32 @@ __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builti
       ++diagW[k];                                                                                                      \
     ++diagL[k];                                                                                                        \
   } while (0)
-#define VR_DIAG_ARGS , unsigned (&diagW)[16], unsigned (&diagL)[16]
-#define VR_DIAG_PASS , diagW, diagL
+// TICK(k): wave time (s_memtime, core clock) since the previous TICK goes to phase k; phaseT = this wave's
+// row of an LDS table, summed into counters[64 + k] at the end of the kernel
+#define TICK(k)                                                                                                        \
+  do {                                                                                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                      \
+    if ((threadIdx.x & 63u) == 0u)                                                                                     \
+      phaseT[k] += now_ - tLast;                                                                                       \
+    tLast = now_;                                                                                                      \
+  } while (0)
+// SUB_START / SUB_STOP(k): a stretch inside divergent code (first active lane books it); part of the enclosing phase
+#define SUB_START const unsigned long long sub0_ = __builtin_amdgcn_s_memtime();
+#define SUB_STOP(k)                                                                                                    \
+  do {                                                                                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                      \
+    const unsigned long long m_ = ballot64(1);                                                                         \
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1)                                                        \
+      phaseT[k] += now_ - sub0_;                                                                                       \
+  } while (0)
+#define VR_DIAG_ARGS , unsigned (&diagW)[16], unsigned (&diagL)[16], unsigned long long *phaseT, unsigned long long &tLast
+#define VR_DIAG_PASS , diagW, diagL, phaseT, tLast
 #else
 #define VR_DIAG_DECL
 #define DIAG(k)
+#define TICK(k)
+#define SUB_START
+#define SUB_STOP(k)
 #define VR_DIAG_ARGS
 #define VR_DIAG_PASS
 #endif
@@ -355,13 +376,15 @@ __device__ __forceinline__ V3 safe_inverse(const V3 &d) {
 }
 
 // closest-hit rule: min t; ties -> boundary first, then lower original id
-__device__ __forceinline__ void hit_update(HitRec &h, bool ok, float t, unsigned orig, unsigned q) {
-  if (ok && (t < h.t || (t == h.t && h.geom == 1 && orig < h.prim))) {
+__device__ __forceinline__ bool hit_update(HitRec &h, bool ok, float t, unsigned orig, unsigned q) {
+  const bool take = ok && (t < h.t || (t == h.t && h.geom == 1 && orig < h.prim));
+  if (take) {
     h.t = t;
     h.geom = 1;
     h.prim = orig;
     h.pos = q;
   }
+  return take;
 }
 
 // Conservative pre-test of a disc from its first record word {c, r} alone: a ray can only pass
@@ -603,6 +626,7 @@ __device__ __forceinline__ void pair_walk_lanes(const TraceParams &p, unsigned *
         parked = parked || park;
       }
     }
+    TICK(2);
     if (ballot64(pend != 0u)) {
       const unsigned first = pend & VR_LEAF_FIRST_MASK;
       const unsigned cnt = pend ? (pend >> 27) & 15u : 0u;
@@ -631,6 +655,7 @@ __device__ __forceinline__ void pair_walk_lanes(const TraceParams &p, unsigned *
       }
       pend = 0u;
     }
+    TICK(3);
     if ((unsigned)__popcll(ballot64(node != VR_END)) < minLanes)
       break;
   }

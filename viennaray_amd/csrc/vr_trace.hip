@@ -450,6 +450,13 @@ trace_kernel(const TraceParams p) {
   unsigned pqSkip = 0, pqFails = 0;         // ... and of packet-query attempts
   bool exhausted = false;
   VR_DIAG_DECL
+#ifdef VR_DIAG
+  __shared__ unsigned long long phaseS[(VR_BLOCK / 64) * 12];
+  unsigned long long *const phaseT = phaseS + (tid >> 6) * 12;
+  if (lane < 12)
+    phaseT[lane] = 0ull;
+  unsigned long long tLast = __builtin_amdgcn_s_memtime();
+#endif
 
   for (;;) {
     // keep the compiler from hoisting the (loop-invariant) LDS wall table into
@@ -524,6 +531,7 @@ trace_kernel(const TraceParams p) {
     }
     if (!ballot64(active))
       break;
+    TICK(0);
 
     // ---- closest hit of a trace segment (rtcIntersect1, rayTraceKernel.hpp:163-167) ----
     // A round: if the whole wave begins a segment together
@@ -579,6 +587,7 @@ trace_kernel(const TraceParams p) {
     } else if (packetSkip) {
       --packetSkip;
     }
+    TICK(1);
     if (!packetDone) {
       const unsigned walking = (unsigned)__popcll(ballot64(active && (ORDERED ? node != VR_END : node < p.numNodes)));
       const unsigned minLanes = (!CARRY || exhausted || walking <= p.walkExit) ? 1u : p.walkExit;
@@ -606,8 +615,10 @@ trace_kernel(const TraceParams p) {
       }
     }
 #endif
+    TICK(3);
     if (fin)
       hit_walls(p, wallS, org, dir, tnear, h); // boundary walls, where one can come before the hit
+    TICK(4);
     // Merge same-disk credits of the wave into one atomic when that is likely to pay: rays of a
     // packet, or — sampled on one lane's target — when a good share of the wave's hits fall on
     // the same primitive (sorted rays on a coarse scene: one vector atomic with 64 lanes on ONE
@@ -651,12 +662,14 @@ trace_kernel(const TraceParams p) {
         if (scattered) {
           // (reflect = true; continue)
         } else if (h.geom == 0) { // boundary, :206-214 + rayBoundary.hpp:29-127
+          SUB_START
           if (++boundaryHits > p.maxBoundaryHits) {
             VR_COUNT(K_TERM, 1);
             active = false;
           } else {
             process_boundary_hit<D>(p, wallS, h.prim, hitPoint, org, rayDirection, dir, active);
           }
+          SUB_STOP(11);
         } else {
           // geometry hit
           V3 geomNormal;
@@ -683,15 +696,17 @@ trace_kernel(const TraceParams p) {
               creditLane = true; // credited after the state machine, for the whole wave at once (pq_credit)
               creditW = wfx;
             } else if (!EXT) {
-              // surfaceCollision, rayParticle.hpp:148-156
-              if (!(p.debugFlags & 1u)) {
-                if (aggregate)
-                  credit_aggregated(fluxAcc, true, h.pos, wfx);
-                else
-                  atomicAdd(&fluxAcc[h.pos], wfx);
-              }
+              // surfaceCollision, rayParticle.hpp:148-156.  Without aggregation the credits of the neighbour
+              // disks are first collected (three in registers; further ones, rare, go out at once) and then issued
+              // together with the closest disk's: on gfx9 a load that follows an atomic waits for that atomic too
+              // (one in-order counter), so an atomic inside the neighbour loop exposed its full L2 round trip to
+              // the next neighbour's loads, iteration after iteration.
+              unsigned cq0 = 0xFFFFFFFFu, cq1 = 0xFFFFFFFFu, cq2 = 0xFFFFFFFFu;
+              if (aggregate && !(p.debugFlags & 1u))
+                credit_aggregated(fluxAcc, true, h.pos, wfx);
               if (GEO == 0 && !(p.debugFlags & 4u)) {
                 // every overlapping neighbour disk is credited the full weight (:271-300)
+                SUB_START
                 const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
                 for (unsigned j = nb; j < ne; ++j) {
                   DIAG(6);
@@ -699,11 +714,31 @@ trace_kernel(const TraceParams p) {
                   const float4 c4 = prims[2 * q];
                   const float4 n4 = prims[2 * q + 1];
                   const bool hitN = local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u);
-                  if (aggregate)
+                  if (aggregate) {
                     credit_aggregated(fluxAcc, hitN, q, wfx);
-                  else if (hitN)
-                    atomicAdd(&fluxAcc[q], wfx);
+                  } else if (hitN) {
+                    if (cq2 != 0xFFFFFFFFu)
+                      atomicAdd(&fluxAcc[q], wfx);
+                    else if (cq1 != 0xFFFFFFFFu)
+                      cq2 = q;
+                    else if (cq0 != 0xFFFFFFFFu)
+                      cq1 = q;
+                    else
+                      cq0 = q;
+                  }
                 }
+                SUB_STOP(8);
+              }
+              if (!aggregate && !(p.debugFlags & 1u)) {
+                SUB_START
+                atomicAdd(&fluxAcc[h.pos], wfx);
+                if (cq0 != 0xFFFFFFFFu)
+                  atomicAdd(&fluxAcc[cq0], wfx);
+                if (cq1 != 0xFFFFFFFFu)
+                  atomicAdd(&fluxAcc[cq1], wfx);
+                if (cq2 != 0xFFFFFFFFu)
+                  atomicAdd(&fluxAcc[cq2], wfx);
+                SUB_STOP(10);
               }
             } else {
               // plug-in particles: Particles::collide decides what each credited primitive's data
@@ -758,6 +793,7 @@ trace_kernel(const TraceParams p) {
                 active = false; // as above: the pending draws die with the ray
               } else {
                 // surfaceReflection, rayParticle.hpp:137-146 / 178-187
+                SUB_START
                 V3 newDir;
                 if (PARTICLE == 0)
                   newDir = reflection_diffuse<D>(geomNormal, rng, cnt[K_TIER2 * VR_BLOCK]);
@@ -790,6 +826,7 @@ trace_kernel(const TraceParams p) {
                     dir = project_dir<D>(rayDirection);
                   }
                 }
+                SUB_STOP(9);
               }
             }
           }
@@ -801,6 +838,7 @@ trace_kernel(const TraceParams p) {
       }
       start = active; // still alive: the next segment begins in the next round
     }
+    TICK(5);
     if (PQ_CREDIT && pqCredit && !(p.debugFlags & 1u)) {
       // ---- surfaceCollision for the round's surface hits, candidate by candidate (wave-uniform):
       // a lane credits candidate q if q is its closest disk, or q is a neighbour of that disk
@@ -834,9 +872,13 @@ trace_kernel(const TraceParams p) {
         }
       }
     }
+    TICK(6);
   }
 
 #ifdef VR_DIAG
+  TICK(7);
+  if (lane < 12 && phaseT[lane])
+    atomicAdd(&p.counters[64 + lane], phaseT[lane]);
   for (int k = 0; k < 16; ++k) {
     const unsigned long long sw = wave_sum(diagW[k]), sl = wave_sum(diagL[k]);
     if (lane == 0 && sl) {
@@ -979,6 +1021,10 @@ __global__ void debug_intersect_kernel(const TraceParams p, const float *org, co
   const V3 o = mk(org[3 * j], org[3 * j + 1], org[3 * j + 2]), d = mk(dir[3 * j], dir[3 * j + 1], dir[3 * j + 2]);
   HitRec h;
   hit_clear(h);
+#ifdef VR_DIAG
+  unsigned long long phaseDummy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tLast = 0ull;
+  unsigned long long *const phaseT = phaseDummy;
+#endif
   if (ordered) {
     unsigned node = 0u, sp = 0u;
     VR_DIAG_DECL
