@@ -224,6 +224,44 @@ def test_ordered_walk_equals_escape_link_walk(geom, monkeypatch):
     both(o2, d3.astype(np.float32))
 
 
+def test_ordered_walk_deep_tree_uses_the_global_stack(monkeypatch):
+    """A caterpillar tree (disk centres in geometric progression along the diagonal: every Morton prefix
+    splits off one disk) is ~60 levels deep; rays along the diagonal meet every box, so the deferred children
+    outgrow the 12 LDS-resident stack entries and the walk continues in its global slab.  Same hits as the
+    escape-link walk, and apply() runs (an overflow would fail it)."""
+    k = np.arange(0, 22)
+    c = (2.0 ** -k)[:, None] * np.ones((1, 3))
+    # a sheet of disks in front of the diagonal so that random rays also find work
+    g = np.stack(np.meshgrid(np.linspace(0, 1, 24), np.linspace(0, 1, 24), [-0.05]), -1).reshape(-1, 3)
+    pts = np.concatenate([c, g]).astype(np.float32)
+    nrm = np.tile(np.array([[0, 0, 1.0]], dtype=np.float32), (len(pts), 1))
+    nrm[: len(k)] = np.array([1, 1, 1.0], dtype=np.float32) / np.sqrt(3.0)
+    t = vr.TraceDisk(3)
+    t.setGeometry(pts, nrm, 0.04)
+    t.setParticleType(vr.DiffuseParticle(0.5, "f"))
+    rng = np.random.default_rng(3)
+    n = 20000
+    o = np.tile(np.array([[1.5, 1.5, 1.5]], dtype=np.float32), (n, 1)) + rng.normal(size=(n, 3)).astype(np.float32) * 0.01
+    d = -np.ones((n, 3)) + rng.normal(size=(n, 3)) * 0.02
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o2 = rng.uniform(-0.2, 1.2, size=(n, 3)).astype(np.float32)
+    d2 = rng.normal(size=(n, 3))
+    d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)
+    for oo, dd in ((o, d), (o2, d2), (-o + 0.5, -d)):
+        monkeypatch.setenv("VR_DEBUG_WALK", "0")
+        g0, p0, t0 = t.debugIntersect(oo, dd)
+        monkeypatch.setenv("VR_DEBUG_WALK", "1")
+        g1, p1, t1 = t.debugIntersect(oo, dd)
+        assert np.array_equal(g0, g1)
+        m = g0 >= 0
+        assert np.array_equal(p0[m], p1[m]) and np.array_equal(t0[m].view(np.uint32), t1[m].view(np.uint32))
+    assert (g0 == 1).sum() > 0
+    t.setNumberOfRaysPerPoint(200)
+    t.setRngSeed(5)
+    t.apply()
+    assert t.getRayTraceInfo().totalRaysTraced > 0
+
+
 # ---------------------------------------------------------------------------
 def test_rng_seed_config_bit_exact():
     """tests/rngSeed/rngSeed.cpp geometry: 21x21 plane, sticking 1, 10 rays/point.

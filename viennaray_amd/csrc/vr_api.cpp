@@ -1227,7 +1227,7 @@ int vr_apply_finish(vr_context *c) {
     return fail(c, VR_E_STATE, "vr_apply_finish: nothing launched");
   VR_HIP(c, hipSetDevice(c->device));
   VR_HIP(c, hipStreamSynchronize(c->stream));
-  unsigned long long cnt[8];
+  unsigned long long cnt[64]; // [0..7] TraceInfo counters, [60] the walk's stack-overflow flag
   VR_HIP(c, hipMemcpy(cnt, c->dCounters.p, sizeof(cnt), hipMemcpyDeviceToHost));
 #ifdef VR_DIAG
   { // lane-occupancy diagnostics of a -DVR_DIAG build (see vr_trace.hip)
@@ -1255,9 +1255,7 @@ int vr_apply_finish(vr_context *c) {
   {
     // the walk's stack ran out (a tree deeper than SD + VR_STACK_GLOBAL levels of deferred children): the
     // result would be wrong, so the apply fails
-    unsigned long long ovf = 0;
-    VR_HIP(c, hipMemcpy(&ovf, c->dCounters.p + 60, 8, hipMemcpyDeviceToHost));
-    if (ovf) {
+    if (cnt[60]) {
       c->launched = false;
       c->prepared = false;
       return fail(c, VR_E_STATE, "BVH traversal stack overflow (degenerate tree): result discarded");

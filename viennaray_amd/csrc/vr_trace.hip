@@ -396,7 +396,7 @@ trace_kernel(const TraceParams p) {
   // per-lane stack of the ordered walk, [entry][lane]; the absorbing flat-scene kernel walks rarely and keeps its
   // 8 waves per SIMD with a short LDS part (deeper entries: global slab)
   constexpr bool ORDERED = MODE != 1; // (MODE 1 walks rarely: it keeps the escape-link walk, one register of state)
-  constexpr int SD = 12;
+  constexpr int SD = VR_STACK_LDS;
   __shared__ unsigned stackS[ORDERED ? SD * VR_BLOCK : 1];
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & 63u;
@@ -1011,7 +1011,7 @@ __global__ void debug_intersect_kernel(const TraceParams p, const float *org, co
                                        unsigned n, int *geomID, unsigned *primID, float *t, int ordered,
                                        unsigned walkStackWaves) {
   __shared__ float wallS[96];
-  __shared__ unsigned stackS[12 * VR_BLOCK]; // (64-thread blocks: lane columns 0..63 of the [entry][VR_BLOCK] layout)
+  __shared__ unsigned stackS[VR_STACK_LDS * VR_BLOCK]; // (64-thread blocks: lane columns 0..63 of the [entry][VR_BLOCK] layout)
   for (unsigned k = threadIdx.x; k < 96; k += blockDim.x)
     wallS[k] = p.wallTable[k];
   __syncthreads();
@@ -1029,7 +1029,7 @@ __global__ void debug_intersect_kernel(const TraceParams p, const float *org, co
     unsigned node = 0u, sp = 0u;
     VR_DIAG_DECL
     // (diagnostic launches are small: the block index serves as the wave index of the global slab; the host bounds it)
-    pair_walk_lanes<GEO, 12>(p, stackS + threadIdx.x, p.walkStack + (size_t)(blockIdx.x % walkStackWaves) * (VR_STACK_GLOBAL * 64u) + threadIdx.x,
+    pair_walk_lanes<GEO, VR_STACK_LDS>(p, stackS + threadIdx.x, p.walkStack + (size_t)(blockIdx.x % walkStackWaves) * (VR_STACK_GLOBAL * 64u) + threadIdx.x,
                              i < n, o, d, tnear[j], h, node, sp, 1u VR_DIAG_PASS);
   } else {
     unsigned node = 0u;

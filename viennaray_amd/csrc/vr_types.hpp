@@ -37,7 +37,11 @@ constexpr unsigned VR_BIN_CAP = 64; // record slots per sort bin (one wavefront)
 constexpr int VR_BLOCK = 256;
 // stack of the ordered per-lane walk: the first entries of a lane live in LDS ([entry][lane], 12 in
 // the kernels that walk a lot, 4 in the absorbing flat-scene kernel), deeper ones in a per-wave global slab
-constexpr unsigned VR_STACK_GLOBAL = 64;
+constexpr unsigned VR_STACK_GLOBAL = 48;
+#ifndef VR_STACK_LDS_ENTRIES
+#define VR_STACK_LDS_ENTRIES 12 // (a -DVR_STACK_LDS_ENTRIES=2 build sends almost every deferred child through the slab: test variant)
+#endif
+constexpr int VR_STACK_LDS = VR_STACK_LDS_ENTRIES;
 
 struct TraceParams {
   // geometry (device pointers)
