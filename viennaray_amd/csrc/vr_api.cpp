@@ -1243,7 +1243,7 @@ int vr_apply_finish(vr_context *c) {
     unsigned long long ph[12];
     VR_HIP(c, hipMemcpy(ph, c->dCounters.p + 64, sizeof(ph), hipMemcpyDeviceToHost));
     static const char *pn[12] = {"refill", "packets", "walk: search", "walk: leaf tests", "walls", "state machine + credit",
-                                 "packet-query credit", "tail", "  (of state machine) neighbour loop", "  (of state machine) reflection + roulette", "  (of state machine) credit of the closest primitive", "  (of state machine) boundary hit"};
+                                 "packet-query credit", "tail", "  (of state machine) neighbour loop", "  (of state machine) reflection + roulette", "  (of state machine) from its start to the back-face test (vote, miss / wall branches, normal fetch)", "  (of state machine) boundary hit"};
     double tot = 0;
     for (int k = 0; k < 8; ++k)
       tot += (double)ph[k];

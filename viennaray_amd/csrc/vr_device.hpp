@@ -83,6 +83,13 @@ __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builti
   } while (0)
 // SUB_START / SUB_STOP(k): a stretch inside divergent code (first active lane books it); part of the enclosing phase
 #define SUB_START const unsigned long long sub0_ = __builtin_amdgcn_s_memtime();
+#define SUB_MARK(k)                                                                                                    \
+  do {                                                                                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                      \
+    const unsigned long long m_ = ballot64(1);                                                                         \
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)m_) - 1)                                                        \
+      phaseT[k] += now_ - tLast;                                                                                       \
+  } while (0)
 #define SUB_STOP(k)                                                                                                    \
   do {                                                                                                                 \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                      \
@@ -97,6 +104,7 @@ __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builti
 #define DIAG(k)
 #define TICK(k)
 #define SUB_START
+#define SUB_MARK(k)
 #define SUB_STOP(k)
 #define VR_DIAG_ARGS
 #define VR_DIAG_PASS
@@ -114,6 +122,27 @@ __device__ __forceinline__ unsigned tea3(unsigned v0, unsigned v1) {
 }
 
 __device__ __forceinline__ u64 mt_step(u64 p, unsigned j) { return 6364136223846793005ull * (p ^ (p >> 62)) + j; }
+// The same step for the generator's seeding chain (step index a literal after unrolling), written over 32-bit
+// halves with the multiplier's halves held in VGPRs: v_mad_u64_u32 can then take the step index as its scalar
+// 64-bit addend (gfx9 VOP3: one scalar source per instruction) — 6 VALU per step (3 of them multiplies)
+// instead of the 7 + a 64-bit add the compiler makes of the one-line form.
+struct MtMul {
+  unsigned al, ah;
+};
+__device__ __forceinline__ MtMul mt_mul_init() {
+  MtMul m{0x4C957F2Du, 0x5851F42Du}; // 6364136223846793005 = 0x5851F42D4C957F2D
+  asm volatile("" : "+v"(m.al), "+v"(m.ah));
+  return m;
+}
+__device__ __forceinline__ u64 mt_step_v(const MtMul &m, u64 p, unsigned j) {
+  const unsigned xh = (unsigned)(p >> 32);
+  const unsigned t = (unsigned)p ^ (xh >> 30); // low word of p ^ (p >> 62); the high word is unchanged
+  u64 r; // = t * al + j, the index in a scalar register pair (written out: LLVM's constant hoisting otherwise
+         //   rebuilds the indices from a base held in VGPRs, at two more VALU per step)
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(t), "v"(m.al), "s"((u64)j) : "vcc");
+  const unsigned hi = (unsigned)(r >> 32) + t * m.ah + xh * m.al;
+  return ((u64)hi << 32) | (unsigned)r;
+}
 __device__ __forceinline__ u64 mt_twist(u64 a, u64 b, u64 c) {
   u64 y = (a & 0xFFFFFFFF80000000ull) | (b & 0x7FFFFFFFull);
   return c ^ (y >> 1) ^ ((b & 1ull) ? 0xB5026F5AA96619E9ull : 0ull);
@@ -149,10 +178,11 @@ __device__ __forceinline__ void rng_resume(Rng &r, unsigned seed, unsigned k, u6
 
 // cold start: 156 steps of the recurrence to reach s[156]
 __device__ __forceinline__ void rng_init(Rng &r, unsigned seed, u64 *scratchLane) {
+  const MtMul m = mt_mul_init();
   u64 x = seed;
 #pragma unroll 39
   for (int j = 1; j <= 156; ++j)
-    x = mt_step(x, j);
+    x = mt_step_v(m, x, j);
   rng_resume(r, seed, 0, (u64)seed, x);
   r.scratch = scratchLane;
 }
@@ -161,24 +191,25 @@ __device__ __forceinline__ void rng_init(Rng &r, unsigned seed, u64 *scratchLane
 // generator needs when the number of draws is known at compile time.  Also returns the
 // streaming cursors {s[K], s[K+156]} for the draws that follow.
 template <int K> __device__ __forceinline__ void mt_first_outputs(unsigned seed, u64 (&out)[K], u64 &lo, u64 &hi) {
+  const MtMul m = mt_mul_init();
   u64 w[K + 1];
   u64 x = seed;
   w[0] = x;
 #pragma unroll
   for (int j = 1; j <= K; ++j) {
-    x = mt_step(x, j);
+    x = mt_step_v(m, x, j);
     w[j] = x;
   }
 #pragma unroll 38 // (152 steps = 4 x 38: the step needs its index as a literal; deeper unrolling loses in the I-cache)
   for (int j = K + 1; j < 156; ++j)
-    x = mt_step(x, j);
+    x = mt_step_v(m, x, j);
 #pragma unroll
   for (int i = 0; i < K; ++i) {
-    x = mt_step(x, 156 + i);
+    x = mt_step_v(m, x, 156 + i);
     out[i] = mt_temper(mt_twist(w[i], w[i + 1], x));
   }
   lo = w[K];
-  hi = mt_step(x, 156 + K);
+  hi = mt_step_v(m, x, 156 + K);
 }
 
 __device__ __noinline__ void rng_tier2_build(Rng &r) {

@@ -680,6 +680,7 @@ trace_kernel(const TraceParams p) {
             geomNormal = mk(prims[4 * h.pos + 1].w, prims[4 * h.pos + 2].w, prims[4 * h.pos + 3].w);
           }
           const bool backfaceHit = vdot(rayDirection, geomNormal) > 0.f; // :224
+          SUB_MARK(10);
           if (backfaceHit) {
             if (GEO == 0 && !hitFromBack) { // first back hit of a disk: let through, :235-240
               hitFromBack = true;
@@ -730,7 +731,6 @@ trace_kernel(const TraceParams p) {
                 SUB_STOP(8);
               }
               if (!aggregate && !(p.debugFlags & 1u)) {
-                SUB_START
                 atomicAdd(&fluxAcc[h.pos], wfx);
                 if (cq0 != 0xFFFFFFFFu)
                   atomicAdd(&fluxAcc[cq0], wfx);
@@ -738,7 +738,6 @@ trace_kernel(const TraceParams p) {
                   atomicAdd(&fluxAcc[cq1], wfx);
                 if (cq2 != 0xFFFFFFFFu)
                   atomicAdd(&fluxAcc[cq2], wfx);
-                SUB_STOP(10);
               }
             } else {
               // plug-in particles: Particles::collide decides what each credited primitive's data
