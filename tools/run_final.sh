@@ -10,6 +10,8 @@ bash tools/pmc_case.sh ${TAG}_c2s01 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup
 bash tools/pmc_case.sh ${TAG}_t3d $GRAFT_REPO_ROOT/tools/case_bench.py trench3d 0.1 4000 1 > gpurun_out/$TAG/pmc_trench3d_s0.1.txt 2>&1
 bash tools/pmc_case.sh ${TAG}_c4 $GRAFT_REPO_ROOT/tools/case_bench.py C4 1 > gpurun_out/$TAG/pmc_C4.txt 2>&1
 cd $GRAFT_REPO_ROOT
+# (on the box: bench.py then finds the counters of the very build it runs; publish again at home from gpurun_out/)
+python3 tools/publish_profile.py gpurun_out/prof_$TAG ${TAG}_box gpurun_out/$TAG/issue_ceiling.json > gpurun_out/$TAG/publish.log 2>&1
 python3 bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err; echo "bench rc=$?"
 bash tools/cases.sh > gpurun_out/$TAG/cases.txt 2>&1; echo "cases rc=$?"
 cat gpurun_out/$TAG/cases.txt
