@@ -463,51 +463,61 @@ trace_kernel(const TraceParams p) {
     // ~100 registers: occupancy matters more than 24 ds_reads per segment
     asm volatile("" ::: "memory");
     // ---- wave-wide compaction / restart: idle lanes pull the next sorted rays ----
-    for (int rep = 0; rep < 8;) {
+    // Two steps: first every idle lane is ASSIGNED a record slot — a wave-uniform walk over the next
+    // bins of the span, no memory but the (rare) grab of a new span — then all of them load at once.
+    // (Loading bin by bin cost one full HBM round trip per bin: a round of the absorbing kernel
+    //  swallows two or three bins.)
+    {
       const unsigned long long idle = ballot64(!active);
-      if (!idle)
-        break;
-      if (curOff >= curCnt) { // current bin used up: next bin of the span, or a new span
-        if (curBin + 1 >= spanEnd || spanEnd == 0) {
-          if (exhausted)
-            break;
-          unsigned long long s = 0;
-          if (lane == 0)
-            s = atomicAdd(p.workCounter, (unsigned long long)p.chunk);
-          s = bcast64(s);
-          if (s >= totalBins) {
-            exhausted = true;
-            break;
+      const unsigned need = (unsigned)__popcll(idle);
+      const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
+      unsigned slot = 0xFFFFFFFFu;
+      unsigned assigned = 0;
+      for (int adv = 0; assigned < need && adv < 12;) {
+        if (curOff >= curCnt) { // current bin used up: next bin of the span, or a new span
+          ++adv;
+          if (curBin + 1 >= spanEnd || spanEnd == 0) {
+            if (exhausted)
+              break;
+            unsigned long long s = 0;
+            if (lane == 0)
+              s = atomicAdd(p.workCounter, (unsigned long long)p.chunk);
+            s = bcast64(s);
+            if (s >= totalBins) {
+              exhausted = true;
+              break;
+            }
+            curBin = spanStart = (unsigned)s;
+            spanEnd = (unsigned)((s + p.chunk < totalBins) ? s + p.chunk : totalBins);
+            // the span's bin counts in one coalesced load (lane i <- bin spanStart + i; chunk <= 64)
+            const unsigned bi = spanStart + lane;
+            spanCounts = (bi < spanEnd && bi < p.numBins) ? p.binCount[bi] : 0u;
+          } else {
+            ++curBin;
           }
-          curBin = spanStart = (unsigned)s;
-          spanEnd = (unsigned)((s + p.chunk < totalBins) ? s + p.chunk : totalBins);
-          // the span's bin counts in one coalesced load (lane i <- bin spanStart + i; chunk <= 64)
-          const unsigned bi = spanStart + lane;
-          spanCounts = (bi < spanEnd && bi < p.numBins) ? p.binCount[bi] : 0u;
-        } else {
-          ++curBin;
+          curOff = 0;
+          if (curBin < p.numBins) {
+            const unsigned c = __shfl(spanCounts, (int)(curBin - spanStart), 64);
+            curCnt = c < p.binCap ? c : p.binCap;
+            curBase = curBin * p.binCap;
+          } else {
+            const unsigned k = (curBin - p.numBins) * p.binCap;
+            curCnt = ovCount - k < p.binCap ? ovCount - k : p.binCap;
+            curBase = p.numBins * p.binCap + k;
+          }
+          curCnt = __builtin_amdgcn_readfirstlane(curCnt);
+          continue;
         }
-        curOff = 0;
-        if (curBin < p.numBins) {
-          const unsigned c = __shfl(spanCounts, (int)(curBin - spanStart), 64);
-          curCnt = c < p.binCap ? c : p.binCap;
-          curBase = curBin * p.binCap;
-        } else {
-          const unsigned k = (curBin - p.numBins) * p.binCap;
-          curCnt = ovCount - k < p.binCap ? ovCount - k : p.binCap;
-          curBase = p.numBins * p.binCap + k;
-        }
-        curCnt = __builtin_amdgcn_readfirstlane(curCnt);
-        continue;
+        const unsigned avail = curCnt - curOff;
+        const unsigned take = avail < need - assigned ? avail : need - assigned;
+        if (!active && rank >= assigned && rank < assigned + take)
+          slot = curBase + curOff + (rank - assigned);
+        curOff += take;
+        assigned += take;
       }
-      ++rep;
-      if (!active) {
+      if (slot != 0xFFFFFFFFu) {
         DIAG(8);
-      }
-      const unsigned rank = __popcll(idle & ((1ull << lane) - 1ull));
-      const unsigned avail = curCnt - curOff;
-      if (!active && rank < avail) {
-        const unsigned j = curBase + curOff + rank;
+        const unsigned j = slot;
         constexpr unsigned REC = ABSORB ? 2 : 3; // float4 per record
         const float4 a = rayAB[REC * (size_t)j];
         const float4 b = rayAB[REC * (size_t)j + 1];
@@ -526,8 +536,6 @@ trace_kernel(const TraceParams p) {
           rng_resume(rng, tea3((unsigned)(p.batchFirst + idxOff), p.seed), __float_as_uint(b.w), cur.x, cur.y);
         }
       }
-      const unsigned nIdle = __popcll(idle);
-      curOff += nIdle < avail ? nIdle : avail;
     }
     if (!ballot64(active))
       break;
