@@ -1007,7 +1007,7 @@ int vr_apply_prepare(vr_context *c) {
     p.pqMaxFrontier = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
   p.pqMaxCand = 24;
   if (const char *e = std::getenv("VR_PQ_CAND"))
-    p.pqMaxCand = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
+    p.pqMaxCand = (uint32_t)std::min(24, std::max(1, std::atoi(e))); // (2 * pqMaxCand + 1 records fit VR_PQ_CANDS)
   {
     float scale = 1e-3f;
     for (int k = 0; k < 3; ++k) {

@@ -816,14 +816,6 @@ __device__ __forceinline__ void wave_minmax6(float &a, float &b, float &c, float
   f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(f), 63));
 }
 
-// v_writelane_b32: lane `dstLane` of `reg` := the wave-uniform value `val`
-__device__ __forceinline__ unsigned lane_write(unsigned reg, unsigned val, int dstLane) {
-  const unsigned sv = (unsigned)__builtin_amdgcn_readfirstlane((int)val);
-  const int sl = __builtin_amdgcn_readfirstlane(dstLane);
-  // (gfx9 allows one SGPR on the constant bus: the lane select goes through M0)
-  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(sv), "s"(sl) : "m0");
-  return reg;
-}
 __device__ __forceinline__ bool local_disc_hit(const V3 &ro, const V3 &rd, const float4 &c4, const V3 &n);
 
 __device__ __forceinline__ float lane_bcast(float v, int srcLane) {
@@ -831,18 +823,19 @@ __device__ __forceinline__ float lane_bcast(float v, int srcLane) {
 }
 
 // What a completed packet query leaves behind for the crediting of disks (pq_credit, vr_trace.hip):
-// candidate c's leaf position and centre live in LANE c of four registers (written with
-// v_writelane, read back wave-uniformly with v_readlane: no memory), and bit c of each lane's
+// candidate c's leaf position and centre are record c of a small per-wave LDS table (written by the
+// lane that holds the candidate's record, read back by all lanes at once: one ds_write_b128 / one
+// broadcast ds_read_b128 per candidate instead of four v_writelane / v_readlane sequences), and bit c of each lane's
 // `local` says whether that lane's ray passes the neighbour test on candidate c
 // (checkLocalIntersection, rayTraceKernel.hpp:462-507).  Every disk a ray can be credited to is
 // among the candidates: the test only passes where the ray crosses the disk, the disk lies in the
 // scene box, and Q covers every participating ray from its origin to where it leaves that box.
 struct PqCands {
-  unsigned pos;  // lane c: leaf position of candidate c
-  float cx, cy, cz;
+  uint4 *rec;    // this wave's candidate records in LDS: {leaf position, centre.xyz as bits}, VR_PQ_CANDS entries
   unsigned long long local;
   unsigned count; // wave-uniform
 };
+constexpr unsigned VR_PQ_CANDS = 52; // >= 2 * pqMaxCand + 1 (pqMaxCand <= 24, vr_api.cpp)
 
 // lst: 128 dwords of LDS private to this wave
 template <int GEO, bool CREDIT>
@@ -989,10 +982,8 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
         hit_update(h, part && ok, t, orig, qq);
         if (CREDIT) {
           const int c = (int)tests;
-          cd.pos = lane_write(cd.pos, qq, c);
-          cd.cx = __uint_as_float(lane_write(__float_as_uint(cd.cx), __float_as_uint(c4.x), c));
-          cd.cy = __uint_as_float(lane_write(__float_as_uint(cd.cy), __float_as_uint(c4.y), c));
-          cd.cz = __uint_as_float(lane_write(__float_as_uint(cd.cz), __float_as_uint(c4.z), c));
+          if ((int)lane == k) // (the lane that loaded the record files it: its r0 is the broadcast c4)
+            cd.rec[c] = make_uint4(qq, __float_as_uint(r0.x), __float_as_uint(r0.y), __float_as_uint(r0.z));
           // (a wave-wide early out between the cheap sign tests and the division / distance part of
           //  these two tests was measured: the extra votes and branches cost more than they save)
           if (part && local_disc_hit(o, d, c4, n))

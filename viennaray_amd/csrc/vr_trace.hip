@@ -380,10 +380,9 @@ trace_kernel(const TraceParams p) {
   // walking the neighbour CSR per lane
   constexpr bool PQ_CREDIT = GEO == 0 && !EXT && (MODE == 1 || MODE == 3);
   PqCands cands;
-  cands.pos = 0u;
-  cands.cx = cands.cy = cands.cz = 0.f;
   cands.local = 0ull;
   cands.count = 0u;
+  cands.rec = nullptr;
   // CARRY: lanes whose BVH walk is still under way when most of the wave is done keep
   // their cursor over the state-machine / refill phase (see the round structure below).
   // The absorbing kernel for flat scenes does without: its rounds are packets, and the extra
@@ -392,13 +391,15 @@ trace_kernel(const TraceParams p) {
   __shared__ float wallS[96];
   // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
   __shared__ unsigned cntS[8 * VR_BLOCK];
-  __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier / candidate lists
+  __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier lists
+  __shared__ uint4 candS[PQ_CREDIT ? (VR_BLOCK / 64) * VR_PQ_CANDS : 1]; // ... and candidate records (pq_credit)
   // per-lane stack of the ordered walk, [entry][lane]; the absorbing flat-scene kernel walks rarely and keeps its
   // 8 waves per SIMD with a short LDS part (deeper entries: global slab)
   constexpr bool ORDERED = MODE != 1; // (MODE 1 walks rarely: it keeps the escape-link walk, one register of state)
   constexpr int SD = VR_STACK_LDS;
   __shared__ unsigned stackS[ORDERED ? SD * VR_BLOCK : 1];
   const unsigned tid = threadIdx.x;
+  cands.rec = candS + (PQ_CREDIT ? (tid >> 6) * VR_PQ_CANDS : 0u);
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
   if (tid < 96)
@@ -855,17 +856,18 @@ trace_kernel(const TraceParams p) {
       if (ballot64(creditLane)) {
         float px = 0.f, py = 0.f, pz = 0.f; // centre of this lane's closest disk
         for (unsigned c = 0; c < cands.count; ++c) {
-          const bool mine = h.pos == (unsigned)__builtin_amdgcn_readlane((int)cands.pos, (int)c);
-          px = mine ? lane_bcast(cands.cx, (int)c) : px;
-          py = mine ? lane_bcast(cands.cy, (int)c) : py;
-          pz = mine ? lane_bcast(cands.cz, (int)c) : pz;
+          const uint4 cr = cands.rec[c]; // (same address in every lane: an LDS broadcast)
+          const bool mine = h.pos == cr.x;
+          px = mine ? __uint_as_float(cr.y) : px;
+          py = mine ? __uint_as_float(cr.z) : py;
+          pz = mine ? __uint_as_float(cr.w) : pz;
         }
         const float dist = p.nbDist, dist2 = dist * dist;
         for (unsigned c = 0; c < cands.count; ++c) {
           DIAG(6);
-          const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)cands.pos, (int)c);
-          const float dx = px - lane_bcast(cands.cx, (int)c), dy = py - lane_bcast(cands.cy, (int)c),
-                      dz = pz - lane_bcast(cands.cz, (int)c);
+          const uint4 cr = cands.rec[c];
+          const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane((int)cr.x);
+          const float dx = px - __uint_as_float(cr.y), dy = py - __uint_as_float(cr.z), dz = pz - __uint_as_float(cr.w);
           bool near = fabsf(dx) <= dist && fabsf(dy) <= dist && (p.geoD == 2 || fabsf(dz) <= dist);
           near = near && ((dx * dx + dy * dy) + dz * dz) <= dist2;
           const bool sel = creditLane && (h.pos == q || (near && ((cands.local >> c) & 1ull)));
