@@ -369,7 +369,7 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 // MODE 3: general kernel for a flat scene: like 0, with the packet query's wave-uniform crediting.
 template <int D, int GEO, int PARTICLE, int MODE>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
-__attribute__((amdgpu_waves_per_eu(MODE == 1 ? 8 : (MODE == 2 ? 7 : 6), MODE == 1 ? 8 : (MODE == 2 ? 7 : 6)))) void
+__attribute__((amdgpu_waves_per_eu(MODE == 1 ? 8 : (MODE == 2 ? 7 : (MODE == 3 ? 5 : 6)), MODE == 1 ? 8 : (MODE == 2 ? 7 : (MODE == 3 ? 5 : 6))))) void
 trace_kernel(const TraceParams p) {
   constexpr bool ABSORB = MODE == 1 || MODE == 2;
   // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
