@@ -116,10 +116,14 @@ template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p
   const float u2 = fold_unit((getc(org, p.secondDir) + getc(dir, p.secondDir) * t - p.lo2) * p.invExt2, p.bc1);
   int c2 = (int)(u2 * (float)p.binT2);
   c2 = c2 < 0 ? 0 : (c2 >= p.binT2 ? p.binT2 - 1 : c2);
-  // 8x8 tiles in row-major order, cells row-major inside a tile: consecutive bins are
-  // spatial neighbours without rounding the grid up to a power of two
+  // 8x8 tiles in row-major order; inside a tile the COLUMNS run in alternating directions (boustrophedon: up
+  // column 0, down column 1, ...), so consecutive bins are always adjacent cells — also from one tile to the next
+  // in a row of tiles (a tile ends bottom right, its neighbour starts bottom left).  A round of the trace kernel
+  // swallows two or three bins; with plain row-major cells one round in four straddled a row end: a packet box
+  // eight cells wide.
   const unsigned tile = (unsigned)(c2 >> 3) * (unsigned)p.binTiles + (unsigned)(c1 >> 3);
-  return tile * 64u + (((unsigned)c2 & 7u) << 3 | ((unsigned)c1 & 7u));
+  const unsigned row = (unsigned)c2 & 7u, col = (unsigned)c1 & 7u;
+  return tile * 64u + (col << 3 | ((col & 1u) ? 7u - row : row));
 }
 
 // ---------------------------------------------------------------------------
@@ -474,7 +478,9 @@ trace_kernel(const TraceParams p) {
       const unsigned rank = (unsigned)__popcll(idle & ((1ull << lane) - 1ull));
       unsigned slot = 0xFFFFFFFFu;
       unsigned assigned = 0;
-      for (int adv = 0; assigned < need && adv < 12;) {
+      // (at most 12 bin changes per round — unless the wave has nothing at all to do: it owns its span, and
+      //  leaving with bins of it unread would lose their rays)
+      for (int adv = 0; assigned < need && (adv < 12 || (need == 64u && assigned == 0u));) {
         if (curOff >= curCnt) { // current bin used up: next bin of the span, or a new span
           ++adv;
           if (curBin + 1 >= spanEnd || spanEnd == 0) {
