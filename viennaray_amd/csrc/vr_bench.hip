@@ -20,11 +20,10 @@
 // in-kernel: delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).
 #include <hip/hip_runtime.h>
 
+#include "vr_device.hpp"
 #include "vr_kernels.hpp"
 
 namespace vr {
-
-typedef unsigned long long u64;
 
 struct IssueOut {
   u64 cycles;   // s_memtime delta of this wave
@@ -60,10 +59,12 @@ template <int KIND> __global__ __launch_bounds__(256) void issue_kernel(unsigned
                    : "+v"(a0)
                    : "v"(m), "v"(c));
     } else if (KIND == 2) {
-      // 32 steps of the mt19937_64 seeding recurrence (compiler's lowering, as in gen_kernel)
+      // 32 steps of the mt19937_64 seeding recurrence, the very step of gen_kernel (mt_step_v: 6 VALU, 3 of
+      // them 32-bit multiplies)
+      const MtMul mm = mt_mul_init();
 #pragma unroll
       for (unsigned j = 1; j <= 32; ++j)
-        x = 6364136223846793005ull * (x ^ (x >> 62)) + j;
+        x = mt_step_v(mm, x, j);
     } else if (KIND == 3) {
       // 32 SALU per pass on four independent registers
       asm volatile(VR_REP8("s_add_u32 %0, %0, %1\n s_and_b32 %1, %1, %2\n s_lshl_b32 %2, %2, 1\n s_xor_b32 %3, %3, %0\n")
