@@ -1140,7 +1140,12 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
     // bins per queue grab: ~1024 rays for big batches, but never so many that a small
     // batch (a short last one, a small launch) is handed to a few waves only
     const uint64_t waves = std::min<uint64_t>(c->grid, ((uint64_t)count + 255) / 256) * (VR_BLOCK / 64);
-    p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, nbBatch / std::max<uint64_t>(waves * 2, 1)));
+    // (a grab of the queue costs two dependent trips to memory: the packet kernels want long spans; the
+    //  general kernel's rounds are long and its bounce chains uneven: shorter spans balance its tail)
+    uint64_t spanBins = c->traceMode == 0 ? 16 : 32;
+    if (const char *e = std::getenv("VR_SPAN_BINS"))
+      spanBins = (uint64_t)std::min(64, std::max(1, std::atoi(e)));
+    p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spanBins, nbBatch / std::max<uint64_t>(waves * 2, 1)));
   }
   const bool keepRng = !c->absorb; // records carry the RNG cursors
   const unsigned slot = c->overlap ? (unsigned)(batchNo & 1) : 0u;
