@@ -93,6 +93,17 @@ def launch_ranks(n, argv):
     return subprocess.call(cmd)
 
 
+def src_sha256():
+    """sha256 over the kernel sources the library is built from (same recipe as tools/prof_summary.py)"""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "viennaray_amd", "csrc")
+    for fn in sorted(os.listdir(src)):
+        if fn.endswith((".hip", ".hpp", ".cpp")) or fn == "Makefile":
+            with open(os.path.join(src, fn), "rb") as fh:
+                h.update(fn.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def lib_sha256():
     import viennaray_amd as vr
     h = hashlib.sha256()
@@ -468,9 +479,12 @@ def roofline(sha, grid, rays, sticking, trace_ms, gen_ms, kernel_name):
     except Exception:
         roof["note"] = "no committed PMC profile (profiles/counters_latest.json)"
         return roof
-    same = (cj.get("lib_sha256") == sha and cj.get("grid") == grid and cj.get("rays") == rays
-            and cj.get("sticking") == sticking)
+    # the profile belongs to this build: same library bytes, or — a rebuild need not be byte-identical —
+    # the same kernel sources
+    same_build = cj.get("lib_sha256") == sha or (cj.get("src_sha256") is not None and cj.get("src_sha256") == src_sha256())
+    same = (same_build and cj.get("grid") == grid and cj.get("rays") == rays and cj.get("sticking") == sticking)
     roof["counts_from"] = {"file": "profiles/counters_latest.json", "lib_sha256": str(cj.get("lib_sha256"))[:16],
+                           "src_sha256": str(cj.get("src_sha256"))[:16],
                            "commit": cj.get("commit"), "matches_running_library_and_workload": bool(same)}
     if not same:
         roof["note"] = "committed PMC profile belongs to another build or workload: not combined with this run's timing"

@@ -86,6 +86,15 @@ try:
     res["lib_sha256"] = h
 except OSError:
     pass
+try:  # ... and the sources it was built from (a rebuild of the same sources may differ in its bytes)
+    hs = hashlib.sha256()
+    src = os.path.join(root, "viennaray_amd", "csrc")
+    for fn in sorted(os.listdir(src)):
+        if fn.endswith((".hip", ".hpp", ".cpp")) or fn == "Makefile":
+            hs.update(fn.encode() + b"\0" + open(os.path.join(src, fn), "rb").read())
+    res["src_sha256"] = hs.hexdigest()
+except OSError:
+    pass
 try:  # the workload the numbers belong to (bench.py only quotes them for the same one)
     line = [l for l in open(os.path.join(d, "stats.log")) if l.startswith("{")][-1]
     cfg = json.loads(line)["config"]
