@@ -557,6 +557,8 @@ SCHEDULING_KNOBS = [
     {"VR_BATCH_RAYS": "40000"},                       # many batches
     {"VR_BIN_CAP": "8", "VR_RAYS_PER_BIN": "16"},     # most rays overflow their bin
     {"VR_RAYS_PER_BIN": "2"},                         # nearly empty bins
+    {"VR_RAYS_PER_BIN": "1", "VR_SPAN_BINS": "64"},   # ... whole spans of them: a wave with nothing to do must walk on
+    {"VR_SPAN_BINS": "1"}, {"VR_SPAN_BINS": "64"},    # work-queue granularity
     {"VR_WALK_EXIT": "1"}, {"VR_WALK_EXIT": "64"},    # no / eager straggler carry-over
     {"VR_WALK_PARK": "1"}, {"VR_WALK_PARK": "100"},   # leaf batching extremes
     {"VR_PACKET_BUDGET": "0"}, {"VR_PACKET_BUDGET": "100000", "VR_PACKET_RATIO": "1000"},
