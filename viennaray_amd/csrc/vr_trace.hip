@@ -16,10 +16,10 @@
 //   trace_kernel    persistent wavefronts pull bins; a lane whose ray ends pulls
 //                   the next one (wave-wide compaction by ballot + prefix
 //                   popcount), so bounce chains of different length do not idle
-//                   the wave.  Per segment: closest hit (wave-uniform packet
-//                   traversal with per-lane fallback, stackless BVH + boundary
-//                   walls), then the reference's state machine
-//                   (rayTraceKernel.hpp:155-335).
+//                   the wave.  Per segment: closest hit (wave-uniform packet query /
+//                   packet traversal, per-lane ordered walk with its stack in LDS as
+//                   the fallback; then the boundary walls), then the reference's
+//                   state machine (rayTraceKernel.hpp:155-335).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
