@@ -1245,14 +1245,15 @@ int vr_apply_finish(vr_context *c) {
       if (dg[2 * k])
         std::fprintf(stderr, "diag %-18s wave-iters %12llu  lane-iters %14llu  (%.1f lanes)\n", names[k], dg[2 * k],
                      dg[2 * k + 1], (double)dg[2 * k + 1] / (double)dg[2 * k]);
-    unsigned long long ph[12];
+    unsigned long long ph[16];
     VR_HIP(c, hipMemcpy(ph, c->dCounters.p + 64, sizeof(ph), hipMemcpyDeviceToHost));
-    static const char *pn[12] = {"refill", "packets", "walk: search", "walk: leaf tests", "walls", "state machine + credit",
-                                 "packet-query credit", "tail", "  (of state machine) neighbour loop", "  (of state machine) reflection + roulette", "  (of state machine) from its start to the back-face test (vote, miss / wall branches, normal fetch)", "  (of state machine) boundary hit"};
+    static const char *pn[16] = {"refill", "packets", "walk: search", "walk: leaf tests", "walls", "state machine + credit",
+                                 "packet-query credit", "tail", "  (of state machine) neighbour loop", "  (of state machine) reflection + roulette", "  (of state machine) from its start to the back-face test (vote, miss / wall branches, normal fetch)", "  (of state machine) boundary hit",
+                                 "  (of state machine) up to the aggregation vote", "  (of state machine) up to the end counters", "-", "-"};
     double tot = 0;
     for (int k = 0; k < 8; ++k)
       tot += (double)ph[k];
-    for (int k = 0; k < 12; ++k)
+    for (int k = 0; k < 16; ++k)
       if (ph[k])
         std::fprintf(stderr, "phase %-24s %5.1f %% of wave time\n", pn[k], 100.0 * (double)ph[k] / tot);
   }

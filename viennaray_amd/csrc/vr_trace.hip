@@ -456,9 +456,9 @@ trace_kernel(const TraceParams p) {
   bool exhausted = false;
   VR_DIAG_DECL
 #ifdef VR_DIAG
-  __shared__ unsigned long long phaseS[(VR_BLOCK / 64) * 12];
-  unsigned long long *const phaseT = phaseS + (tid >> 6) * 12;
-  if (lane < 12)
+  __shared__ unsigned long long phaseS[(VR_BLOCK / 64) * 16];
+  unsigned long long *const phaseT = phaseS + (tid >> 6) * 16;
+  if (lane < 16)
     phaseT[lane] = 0ull;
   unsigned long long tLast = __builtin_amdgcn_s_memtime();
 #endif
@@ -651,6 +651,7 @@ trace_kernel(const TraceParams p) {
 
     bool creditLane = false;
     u64 creditW = 0;
+    SUB_MARK(12); // (since the walls: the aggregation vote)
     if (fin) {
       DIAG(5);
       // ---- the reference's state machine for this segment (rayTraceKernel.hpp:169-335) ----
@@ -846,6 +847,7 @@ trace_kernel(const TraceParams p) {
           }
         }
       }
+      SUB_MARK(13); // (since the walls: everything but the per-ray end counters)
       if (!active) {
         VR_COUNT(K_BOUNDARY, boundaryHits);
         VR_COUNT(K_REFL, numReflections);
@@ -892,7 +894,7 @@ trace_kernel(const TraceParams p) {
 
 #ifdef VR_DIAG
   TICK(7);
-  if (lane < 12 && phaseT[lane])
+  if (lane < 16 && phaseT[lane])
     atomicAdd(&p.counters[64 + lane], phaseT[lane]);
   for (int k = 0; k < 16; ++k) {
     const unsigned long long sw = wave_sum(diagW[k]), sl = wave_sum(diagL[k]);
