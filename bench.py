@@ -382,7 +382,8 @@ def main():
                        "rays_per_gpu": rays_rank, "total_rays": total_rays, "grid": n, "sticking": args.sticking,
                        "kernel_mode": {0: "general (reflection + roulette + RNG)", 1: "absorbing, flat scene",
                                        2: "absorbing, structured scene",
-                                       3: "general, flat scene (packet-query crediting)"}[mode],
+                                       3: "general, flat scene (packet-query crediting)",
+                                       4: "general, scene resident in LDS"}.get(mode, str(mode)),
                        "parallelism": f"ray-range shards x{world}, BVH replicated, int64 flux all-reduce"},
             "device_pipeline_ms": round(kavg, 4), "trace_kernel_ms": round(tavg, 4), "gen_kernel_ms": round(gavg, 4),
             "segments_per_step": int(np.mean(segs)), "Msegments_per_s": round(np.mean(segs) / (kavg * 1e-3) / 1e6, 2),

@@ -168,8 +168,8 @@ uint32_t vr_num_data(const vr_context *ctx);
 int vr_get_flux_data(vr_context *ctx, uint32_t dataIdx, float *out, uint32_t n);
 int vr_get_trace_info(const vr_context *ctx, vr_trace_info *out);
 /* which trace_kernel variant the last vr_apply_prepare selected: 0 general (reflection, roulette,
- * RNG), 1 absorbing + flat scene, 2 absorbing + structured scene, 3 general + flat scene
- *                                                                           */
+ * RNG), 1 absorbing + flat scene, 2 absorbing + structured scene, 3 general + flat scene,
+ * 4 general, scene of a few hundred primitives resident in LDS             */
 int vr_get_trace_mode(const vr_context *ctx, int32_t *mode);
 /* normalizeFlux / smoothFlux (rayTraceDisk.hpp:103-193, rayTraceTriangle.hpp:92-136), in place on
  * a caller buffer; both run as HIP kernels on the resident areas / neighbourhood (upload, kernel,

@@ -559,6 +559,7 @@ SCHEDULING_KNOBS = [
     {"VR_RAYS_PER_BIN": "2"},                         # nearly empty bins
     {"VR_RAYS_PER_BIN": "1", "VR_SPAN_BINS": "64"},   # ... whole spans of them: a wave with nothing to do must walk on
     {"VR_SPAN_BINS": "1"}, {"VR_SPAN_BINS": "64"},    # work-queue granularity
+    {"VR_SMALL_SCENE": "0"},                          # small scenes from HBM instead of resident in LDS (MODE 4 off)
     {"VR_WALK_EXIT": "1"}, {"VR_WALK_EXIT": "64"},    # no / eager straggler carry-over
     {"VR_WALK_PARK": "1"}, {"VR_WALK_PARK": "100"},   # leaf batching extremes
     {"VR_PACKET_BUDGET": "0"}, {"VR_PACKET_BUDGET": "100000", "VR_PACKET_RATIO": "1000"},
@@ -623,6 +624,38 @@ def test_scheduling_knobs_do_not_change_results(geom, sticking, monkeypatch):
             f, i = run()
         assert i == i0, knobs
         assert (f == f0).all(), knobs
+
+
+@pytest.mark.parametrize("sticking", [1.0, 0.3])
+@pytest.mark.parametrize("geom", ["trench2d", "sphere"])
+def test_small_scene_kernel_resident_in_lds(geom, sticking, monkeypatch):
+    """Scenes of a few hundred primitives run trace_kernel MODE 4 (pair nodes, records, neighbourhood and flux
+    accumulators staged in LDS).  Same accumulator bits and counters as the kernels that read the scene from HBM,
+    and the oracle's counters."""
+    def run():
+        if geom == "trench2d":
+            gd, p, n = trench2d()
+            t = vr.TraceDisk(2)
+            t.setGeometry(p, n, gd)
+            t.setSourceDirection(TD.POS_Y)
+            t.setBoundaryConditions([BC.REFLECTIVE_BOUNDARY] * 2)
+        else:
+            gd, p, n = sphere3d()
+            t = vr.TraceDisk(3)
+            t.setGeometry(p, n, gd)
+            t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+        t.setParticleType(vr.DiffuseParticle(sticking, "flux"))
+        t.setNumberOfRaysPerPoint(3000)
+        t.setRngSeed(321)
+        t.apply()
+        return t.getFluxF64(), info_dict(t), t.traceMode()
+
+    f1, i1, m1 = run()
+    assert m1 == 4
+    monkeypatch.setenv("VR_SMALL_SCENE", "0")
+    f0, i0, m0 = run()
+    assert m0 in (0, 1, 2, 3)
+    assert i0 == i1 and (f0 == f1).all()
 
 
 # ---------------------------------------------------------------------------

@@ -882,6 +882,37 @@ int vr_apply_prepare(vr_context *c) {
   if (extended)
     c->absorb = false;
   c->kernelParticle = extended ? (int)P_EXT : c->particleKind;
+  // a scene of a few hundred primitives goes into LDS as a whole (MODE 4: the general kernel — also for
+  // absorbing particles —, the built-in particles, one data label, no per-material sticking): pair nodes,
+  // records, neighbourhood, accumulators
+  bool smallScene = false;
+  {
+    const uint32_t recB = c->geo.geo == 0 ? 32u : 64u;
+    uint32_t off[5], o = 0, nbTotal = 0;
+    if (c->geo.geo == 0 && N > 0) {
+      if (c->hostNeighborsValid && !c->geo.nbOff.empty())
+        nbTotal = c->geo.nbOff.back();
+      else
+        VR_HIP(c, hipMemcpy(&nbTotal, c->dNbOff.p + N, 4, hipMemcpyDeviceToHost));
+    }
+    auto put = [&](int k, size_t bytes) {
+      off[k] = o;
+      o += (uint32_t)((bytes + 15) & ~(size_t)15);
+    };
+    put(0, (size_t)c->numNodes * 32);
+    put(1, (size_t)N * recB);
+    put(2, ((size_t)N + 1) * 4);
+    put(3, (size_t)nbTotal * 4);
+    put(4, (size_t)N * 8);
+    smallScene = o <= VR_SMALL_LDS && !extended && !c->havePrimSticking && c->numData == 1 && c->numNodes > 0;
+    if (const char *e = std::getenv("VR_SMALL_SCENE"))
+      smallScene = smallScene && std::atoi(e) != 0;
+    for (int k = 0; k < 5; ++k)
+      p.smallOff[k] = off[k];
+    p.smallNb = nbTotal;
+    if (smallScene)
+      c->absorb = false; // (ray records with the RNG cursors: the general kernel reads them)
+  }
   // accumulators: one plane per data label, each replicated accReplicas times
   if (c->accPlanes != c->numData) {
     VR_HIP(c, c->dFluxAcc.ensure((size_t)c->accStride * c->accReplicas * c->numData));
@@ -959,6 +990,8 @@ int vr_apply_prepare(vr_context *c) {
     if (const char *e = std::getenv("VR_ABSORB_CARRY"))
       if (c->absorb)
         c->traceMode = std::atoi(e) ? 2 : 1;
+    if (smallScene)
+      c->traceMode = 4;
     int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->kernelParticle, c->traceMode));
     if (c->overlap && blocks > 4)
       blocks -= 2; // leave wave slots for the concurrently running generator / sorter

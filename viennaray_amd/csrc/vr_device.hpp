@@ -569,12 +569,12 @@ template <int SD> __device__ __forceinline__ unsigned walk_pop(const unsigned *s
 
 // stackS: this lane's column of the LDS stack (entry e at stackS[e * VR_BLOCK]); stackG: this lane's column of
 // the wave's global slab (entry e at stackG[e * 64])
+// pnodes / prims: the pair nodes and primitive records — global memory, or the LDS copies of MODE 4
 template <int GEO, int SD>
-__device__ __forceinline__ void pair_walk_lanes(const TraceParams &p, unsigned *stackS, unsigned *stackG, bool part,
-                                                const V3 &o, const V3 &d, float tnear, HitRec &h, unsigned &node,
-                                                unsigned &sp, unsigned minLanes VR_DIAG_ARGS) {
-  const uint4 *__restrict__ pnodes = reinterpret_cast<const uint4 *>(p.pnodes);
-  const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
+__device__ __forceinline__ void pair_walk_lanes(const TraceParams &p, const uint4 *__restrict__ pnodes,
+                                                const float4 *__restrict__ prims, unsigned *stackS, unsigned *stackG,
+                                                bool part, const V3 &o, const V3 &d, float tnear, HitRec &h,
+                                                unsigned &node, unsigned &sp, unsigned minLanes VR_DIAG_ARGS) {
   const V3 inv = safe_inverse(V3{d.x * p.qscale[0], d.y * p.qscale[1], d.z * p.qscale[2]});
   const V3 oi = V3{(o.x - p.qbase[0]) * p.qscale[0] * inv.x, (o.y - p.qbase[1]) * p.qscale[1] * inv.y,
                    (o.z - p.qbase[2]) * p.qscale[2] * inv.z};

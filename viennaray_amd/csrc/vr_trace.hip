@@ -371,10 +371,15 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 // MODE 0: general kernel.  MODE 1: absorbing, flat scene (packets carry the load).  MODE 2:
 // absorbing, structured scene (most rounds end in per-lane walks): straggler carry-over on.
 // MODE 3: general kernel for a flat scene: like 0, with the packet query's wave-uniform crediting.
-template <int D, int GEO, int PARTICLE, int MODE>
+// MODE 4: MODE 0 for scenes of a few hundred primitives (2-D simulations): pair nodes, primitive records,
+// neighbourhood and flux accumulators are staged in LDS (VR_SMALL_LDS bytes per block) and every access of the
+// round but the ray records stays there; no packets (a per-lane walk over LDS nodes is cheaper than their set-up).
+template <int D, int GEO, int PARTICLE, int MODE_>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
-__attribute__((amdgpu_waves_per_eu(MODE == 1 ? 8 : (MODE == 2 ? 7 : (MODE == 3 ? 5 : 6)), MODE == 1 ? 8 : (MODE == 2 ? 7 : (MODE == 3 ? 5 : 6))))) void
+__attribute__((amdgpu_waves_per_eu(MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? 5 : (MODE_ == 4 ? 5 : 6))), MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? 5 : (MODE_ == 4 ? 5 : 6)))))) void
 trace_kernel(const TraceParams p) {
+  constexpr bool SMALL = MODE_ == 4;
+  constexpr int MODE = SMALL ? 0 : MODE_;
   constexpr bool ABSORB = MODE == 1 || MODE == 2;
   // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
   // extended kernel — particle kind, data labels, WDIST crediting and mean-free-path scattering
@@ -400,8 +405,10 @@ trace_kernel(const TraceParams p) {
   // per-lane stack of the ordered walk, [entry][lane]; the absorbing flat-scene kernel walks rarely and keeps its
   // 8 waves per SIMD with a short LDS part (deeper entries: global slab)
   constexpr bool ORDERED = MODE != 1; // (MODE 1 walks rarely: it keeps the escape-link walk, one register of state)
-  constexpr int SD = VR_STACK_LDS;
+  constexpr int SD = SMALL ? VR_SMALL_STACK : VR_STACK_LDS;
   __shared__ unsigned stackS[ORDERED ? SD * VR_BLOCK : 1];
+  __shared__ uint4 sceneS[SMALL ? VR_SMALL_LDS / 16 : 1];
+  unsigned char *const sceneB = reinterpret_cast<unsigned char *>(sceneS);
   const unsigned tid = threadIdx.x;
   cands.rec = candS + (PQ_CREDIT ? (tid >> 6) * VR_PQ_CANDS : 0u);
   const unsigned lane = tid & 63u;
@@ -411,14 +418,41 @@ trace_kernel(const TraceParams p) {
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     cntS[k * VR_BLOCK + tid] = 0u;
+  if (SMALL) {
+    // stage the scene (the offsets are multiples of 16 bytes; vr_apply_prepare checked that it fits)
+    const uint4 *gn = reinterpret_cast<const uint4 *>(p.pnodes);
+    uint4 *ln = reinterpret_cast<uint4 *>(sceneB + p.smallOff[0]);
+    for (unsigned k = tid; k < 2u * p.numNodes; k += VR_BLOCK)
+      ln[k] = gn[k];
+    const uint4 *gp = reinterpret_cast<const uint4 *>(p.prims);
+    uint4 *lp = reinterpret_cast<uint4 *>(sceneB + p.smallOff[1]);
+    for (unsigned k = tid; k < (GEO == 0 ? 2u : 4u) * p.numPrims; k += VR_BLOCK)
+      lp[k] = gp[k];
+    unsigned *lo = reinterpret_cast<unsigned *>(sceneB + p.smallOff[2]);
+    for (unsigned k = tid; k <= p.numPrims; k += VR_BLOCK)
+      lo[k] = p.nbOff[k];
+    unsigned *li = reinterpret_cast<unsigned *>(sceneB + p.smallOff[3]);
+    for (unsigned k = tid; k < p.smallNb; k += VR_BLOCK)
+      li[k] = p.nbIds[k];
+    unsigned long long *lf = reinterpret_cast<unsigned long long *>(sceneB + p.smallOff[4]);
+    for (unsigned k = tid; k < p.numPrims; k += VR_BLOCK)
+      lf[k] = 0ull;
+  }
   __syncthreads();
   unsigned *const cnt = cntS + tid; // counter k of this lane: cnt[k * VR_BLOCK]
   enum { K_TRACES = 0, K_NONGEO, K_GEO, K_BOUNDARY, K_REFL, K_TERM, K_TIER2, K_PARTICLE };
 #define VR_COUNT(k, v) atomicAdd(&cnt[(k) * VR_BLOCK], (unsigned)(v))
 
-  const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
+  // scene data: global memory, or (MODE 4) the block's LDS copies
+  const float4 *__restrict__ prims = SMALL ? reinterpret_cast<const float4 *>(sceneB + p.smallOff[1])
+                                           : reinterpret_cast<const float4 *>(p.prims);
+  const uint4 *__restrict__ pnodes = SMALL ? reinterpret_cast<const uint4 *>(sceneB + p.smallOff[0])
+                                           : reinterpret_cast<const uint4 *>(p.pnodes);
+  const unsigned *__restrict__ nbOff = SMALL ? reinterpret_cast<const unsigned *>(sceneB + p.smallOff[2]) : p.nbOff;
+  const unsigned *__restrict__ nbIds = SMALL ? reinterpret_cast<const unsigned *>(sceneB + p.smallOff[3]) : p.nbIds;
   const float4 *__restrict__ rayAB = reinterpret_cast<const float4 *>(p.slotRec);
-  unsigned long long *const fluxAcc = p.fluxAcc + (size_t)(blockIdx.x & p.accMask) * p.accStride; // this block's replica
+  unsigned long long *const fluxGlobal = p.fluxAcc + (size_t)(blockIdx.x & p.accMask) * p.accStride; // this block's replica
+  unsigned long long *const fluxAcc = SMALL ? reinterpret_cast<unsigned long long *>(sceneB + p.smallOff[4]) : fluxGlobal;
   const float tnear = 1e-4f; // rayUtil.hpp:229-231
 
   // per-lane ray state
@@ -568,11 +602,11 @@ trace_kernel(const TraceParams p) {
     }
     const unsigned long long carried = CARRY ? ballot64(active && !start) : 0ull;
     start = false;
-    const bool usePacket =
+    const bool usePacket = !SMALL &&
         !(p.debugFlags & 32u) && carried == 0ull && packetSkip == 0 && __popcll(ballot64(active)) >= 8;
     bool packetDone = false;
     bool pqCredit = false; // this round's surface hits are credited from the packet's candidate list
-    if (usePacket && p.wide && !(p.debugFlags & 128u)) {
+    if (!SMALL && usePacket && p.wide && !(p.debugFlags & 128u)) {
       // first choice: the box query (one wide-tree search for the whole wave)
       if (pqSkip == 0) {
         if (active) {
@@ -592,7 +626,7 @@ trace_kernel(const TraceParams p) {
         --pqSkip;
       }
     }
-    if (usePacket && !packetDone) {
+    if (!SMALL && usePacket && !packetDone) {
       packetDone = bvh_hit_packet<GEO>(p, active, org, dir, tnear, h, p.packetBudget, p.packetRatio VR_DIAG_PASS);
       // a wave whose rays have scattered stops paying for hopeless packets for a while
       packetFails = packetDone ? 0u : (packetFails < 6u ? packetFails + 1u : 6u);
@@ -607,7 +641,7 @@ trace_kernel(const TraceParams p) {
       const unsigned walking = (unsigned)__popcll(ballot64(active && (ORDERED ? node != VR_END : node < p.numNodes)));
       const unsigned minLanes = (!CARRY || exhausted || walking <= p.walkExit) ? 1u : p.walkExit;
       if (ORDERED)
-        pair_walk_lanes<GEO, SD>(p, stackS + tid, stackG, active, org, dir, tnear, h, node, sp, minLanes VR_DIAG_PASS);
+        pair_walk_lanes<GEO, SD>(p, pnodes, prims, stackS + tid, stackG, active, org, dir, tnear, h, node, sp, minLanes VR_DIAG_PASS);
       else
         bvh_walk_lanes<GEO>(p, active, org, dir, tnear, h, node, minLanes VR_DIAG_PASS);
     }
@@ -724,10 +758,10 @@ trace_kernel(const TraceParams p) {
               if (GEO == 0 && !(p.debugFlags & 4u)) {
                 // every overlapping neighbour disk is credited the full weight (:271-300)
                 SUB_START
-                const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
+                const unsigned nb = nbOff[h.pos], ne = nbOff[h.pos + 1];
                 for (unsigned j = nb; j < ne; ++j) {
                   DIAG(6);
-                  const unsigned q = p.nbIds[j];
+                  const unsigned q = nbIds[j];
                   const float4 c4 = prims[2 * q];
                   const float4 n4 = prims[2 * q + 1];
                   const bool hitN = local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u);
@@ -766,7 +800,7 @@ trace_kernel(const TraceParams p) {
                 });
               };
               if (GEO == 0) {
-                const unsigned nb = p.nbOff[h.pos], ne = p.nbOff[h.pos + 1];
+                const unsigned nb = nbOff[h.pos], ne = nbOff[h.pos + 1];
                 float invSum = 0.f, dClosest = 0.f;
                 unsigned numHit = 1;
                 if (p.useWdist) {
@@ -775,7 +809,7 @@ trace_kernel(const TraceParams p) {
                   dClosest = sqrtf(vdot(dv, dv)) + 1e-6f;
                   invSum = 0.f + 1.f / dClosest;
                   for (unsigned j = nb; j < ne; ++j) {
-                    const unsigned q = p.nbIds[j];
+                    const unsigned q = nbIds[j];
                     const float4 n4 = prims[2 * q + 1];
                     float dist;
                     if (local_disc_hit_dist(org, dir, prims[2 * q], mk(n4.x, n4.y, n4.z), dist)) {
@@ -786,7 +820,7 @@ trace_kernel(const TraceParams p) {
                 }
                 creditTo(h.pos, p.useWdist ? rayWeight / dClosest / invSum * (float)numHit : rayWeight, geomNormal);
                 for (unsigned j = nb; j < ne; ++j) {
-                  const unsigned q = p.nbIds[j];
+                  const unsigned q = nbIds[j];
                   const float4 n4 = prims[2 * q + 1];
                   const V3 nq = mk(n4.x, n4.y, n4.z);
                   float dist;
@@ -892,6 +926,13 @@ trace_kernel(const TraceParams p) {
     TICK(6);
   }
 
+  if (SMALL) {
+    // every wave of the block has left the loop: the block's LDS accumulators go to its replica in HBM
+    __syncthreads();
+    for (unsigned k = tid; k < p.numPrims; k += VR_BLOCK)
+      if (fluxAcc[k])
+        atomicAdd(&fluxGlobal[k], fluxAcc[k]);
+  }
 #ifdef VR_DIAG
   TICK(7);
   if (lane < 16 && phaseT[lane])
@@ -966,6 +1007,8 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 2>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
     hipLaunchKernelGGL((trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  else if (mode == 4 && PARTICLE != P_EXT)
+    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE == P_EXT ? 0 : PARTICLE, 4>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else
     hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   return hipGetLastError();
@@ -1009,6 +1052,8 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode) {
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 2>, VR_BLOCK, 0);
   else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>, VR_BLOCK, 0);
+  else if (mode == 4 && PARTICLE != P_EXT)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE == P_EXT ? 0 : PARTICLE, 4>, VR_BLOCK, 0);
   else
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 0>, VR_BLOCK, 0);
   return e == hipSuccess ? nb : 2;
@@ -1046,7 +1091,8 @@ __global__ void debug_intersect_kernel(const TraceParams p, const float *org, co
     unsigned node = 0u, sp = 0u;
     VR_DIAG_DECL
     // (diagnostic launches are small: the block index serves as the wave index of the global slab; the host bounds it)
-    pair_walk_lanes<GEO, VR_STACK_LDS>(p, stackS + threadIdx.x, p.walkStack + (size_t)(blockIdx.x % walkStackWaves) * (VR_STACK_GLOBAL * 64u) + threadIdx.x,
+    pair_walk_lanes<GEO, VR_STACK_LDS>(p, reinterpret_cast<const uint4 *>(p.pnodes), reinterpret_cast<const float4 *>(p.prims),
+                                       stackS + threadIdx.x, p.walkStack + (size_t)(blockIdx.x % walkStackWaves) * (VR_STACK_GLOBAL * 64u) + threadIdx.x,
                              i < n, o, d, tnear[j], h, node, sp, 1u VR_DIAG_PASS);
   } else {
     unsigned node = 0u;

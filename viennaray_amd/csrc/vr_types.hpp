@@ -42,6 +42,10 @@ constexpr unsigned VR_STACK_GLOBAL = 48;
 #define VR_STACK_LDS_ENTRIES 12 // (a -DVR_STACK_LDS_ENTRIES=2 build sends almost every deferred child through the slab: test variant)
 #endif
 constexpr int VR_STACK_LDS = VR_STACK_LDS_ENTRIES;
+// scenes of a few hundred primitives (2-D simulations) live in LDS as a whole — pair nodes, primitive records,
+// neighbourhood, flux accumulators: trace_kernel MODE 4 stages this many bytes per block
+constexpr unsigned VR_SMALL_LDS = 16896;
+constexpr int VR_SMALL_STACK = 6; // LDS stack entries of that kernel (its trees are shallow)
 
 struct TraceParams {
   // geometry (device pointers)
@@ -63,6 +67,9 @@ struct TraceParams {
   float pqPad;                         // outward padding of the packet's box (float rounding of the clip)
   float nbDist;                        // neighbourhood radius = 2 x disk radius (rayGeometryDisk.hpp:191-192)
   int32_t geoD;                        // dimension of the geometry (2: z does not enter the neighbour test's boxes)
+  // MODE 4 (scene resident in LDS): byte offsets of {pair nodes, primitive records, nbOff, nbIds, flux
+  // accumulators} inside the block's VR_SMALL_LDS buffer, and the number of neighbour ids
+  uint32_t smallOff[5], smallNb;
   const uint32_t *nbOff;      // [numPrims+1], disk neighbourhood CSR (leaf order)
   const uint32_t *nbIds;      // leaf positions
   const float *primSticking;  // optional [numPrims] (leaf order) or nullptr
