@@ -910,6 +910,7 @@ int vr_apply_prepare(vr_context *c) {
     for (int k = 0; k < 5; ++k)
       p.smallOff[k] = off[k];
     p.smallNb = nbTotal;
+    p.smallBytes = (o + 255u) & ~255u;
     if (smallScene)
       c->absorb = false; // (ray records with the RNG cursors: the general kernel reads them)
   }
@@ -992,7 +993,7 @@ int vr_apply_prepare(vr_context *c) {
         c->traceMode = std::atoi(e) ? 2 : 1;
     if (smallScene)
       c->traceMode = 4;
-    int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->kernelParticle, c->traceMode));
+    int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->kernelParticle, c->traceMode, p.smallBytes));
     if (c->overlap && blocks > 4)
       blocks -= 2; // leave wave slots for the concurrently running generator / sorter
     if (const char *e = std::getenv("VR_TRACE_BLOCKS"))

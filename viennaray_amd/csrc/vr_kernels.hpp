@@ -12,7 +12,7 @@ hipError_t launch_scan(unsigned *data, unsigned n, unsigned *tmp, hipStream_t s)
 hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int mode, unsigned grid,
                         hipStream_t s);
 // resident 256-thread blocks per CU of the trace kernel instantiation (occupancy API)
-int trace_blocks_per_cu(int D, int geo, int particle, int mode);
+int trace_blocks_per_cu(int D, int geo, int particle, int mode, unsigned smallBytes);
 hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *org, const float *dir,
                                   const float *tnear, unsigned n, int *geomID, unsigned *primID, float *t, int ordered,
                                   unsigned walkStackWaves, hipStream_t s);

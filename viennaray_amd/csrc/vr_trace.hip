@@ -407,7 +407,9 @@ trace_kernel(const TraceParams p) {
   constexpr bool ORDERED = MODE != 1; // (MODE 1 walks rarely: it keeps the escape-link walk, one register of state)
   constexpr int SD = SMALL ? VR_SMALL_STACK : VR_STACK_LDS;
   __shared__ unsigned stackS[ORDERED ? SD * VR_BLOCK : 1];
-  __shared__ uint4 sceneS[SMALL ? VR_SMALL_LDS / 16 : 1];
+  // (MODE 4: the scene copy is the kernel's dynamic LDS — smallBytes of it, so a smaller scene leaves room for a
+  //  fifth block per CU)
+  extern __shared__ uint4 sceneS[];
   unsigned char *const sceneB = reinterpret_cast<unsigned char *>(sceneS);
   const unsigned tid = threadIdx.x;
   cands.rec = candS + (PQ_CREDIT ? (tid >> 6) * VR_PQ_CANDS : 0u);
@@ -1008,7 +1010,7 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
   else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
     hipLaunchKernelGGL((trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 4 && PARTICLE != P_EXT)
-    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE == P_EXT ? 0 : PARTICLE, 4>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE == P_EXT ? 0 : PARTICLE, 4>), dim3(grid), dim3(VR_BLOCK), p.smallBytes, s, p);
   else
     hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   return hipGetLastError();
@@ -1043,7 +1045,7 @@ hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int 
   });
 }
 
-template <int D, int GEO, int PARTICLE> static int occ_t(int mode) {
+template <int D, int GEO, int PARTICLE> static int occ_t(int mode, unsigned smallBytes) {
   int nb = 0;
   hipError_t e;
   if (mode == 1)
@@ -1053,17 +1055,17 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode) {
   else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>, VR_BLOCK, 0);
   else if (mode == 4 && PARTICLE != P_EXT)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE == P_EXT ? 0 : PARTICLE, 4>, VR_BLOCK, 0);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE == P_EXT ? 0 : PARTICLE, 4>, VR_BLOCK, smallBytes);
   else
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 0>, VR_BLOCK, 0);
   return e == hipSuccess ? nb : 2;
 }
 
-int trace_blocks_per_cu(int D, int geo, int particle, int mode) {
+int trace_blocks_per_cu(int D, int geo, int particle, int mode, unsigned smallBytes) {
   if (mode == 1 || mode == 2)
     particle = 0;
   return dispatch_variant(D, geo, particle, [&](auto d, auto g, auto pt) {
-    return occ_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(mode);
+    return occ_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(mode, smallBytes);
   });
 }
 

@@ -43,8 +43,8 @@ constexpr unsigned VR_STACK_GLOBAL = 48;
 #endif
 constexpr int VR_STACK_LDS = VR_STACK_LDS_ENTRIES;
 // scenes of a few hundred primitives (2-D simulations) live in LDS as a whole — pair nodes, primitive records,
-// neighbourhood, flux accumulators: trace_kernel MODE 4 stages this many bytes per block
-constexpr unsigned VR_SMALL_LDS = 16896;
+// neighbourhood, flux accumulators: trace_kernel MODE 4 stages up to this many bytes per block (dynamic LDS)
+constexpr unsigned VR_SMALL_LDS = 25600; // (up to 17.5 KB: five blocks per CU; up to this: four, still ahead of the HBM path)
 constexpr int VR_SMALL_STACK = 6; // LDS stack entries of that kernel (its trees are shallow)
 
 struct TraceParams {
@@ -69,7 +69,7 @@ struct TraceParams {
   int32_t geoD;                        // dimension of the geometry (2: z does not enter the neighbour test's boxes)
   // MODE 4 (scene resident in LDS): byte offsets of {pair nodes, primitive records, nbOff, nbIds, flux
   // accumulators} inside the block's VR_SMALL_LDS buffer, and the number of neighbour ids
-  uint32_t smallOff[5], smallNb;
+  uint32_t smallOff[5], smallNb, smallBytes;
   const uint32_t *nbOff;      // [numPrims+1], disk neighbourhood CSR (leaf order)
   const uint32_t *nbIds;      // leaf positions
   const float *primSticking;  // optional [numPrims] (leaf order) or nullptr
