@@ -111,6 +111,7 @@ struct vr_context {
   DevBuf<float> dAreas, dFluxTmp;     // exposed area per primitive (caller's order); normalisation scratch
   bool areasValid = false;
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
+  uint32_t nbTotal = 0;               // entries of the resident neighbourhood CSR
   DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
   size_t scratchWaves = 0;
   // flux accumulators are replicated accReplicas times (power of two, stride accStride
@@ -557,6 +558,7 @@ static int build_scene(vr_context *c) {
     VR_HIP(c, c->dNodes.ensure(c->bvh.nodes.size()));
     VR_HIP(c, c->dPrims.ensure(prims.size()));
     VR_HIP(c, c->dNbIds.ensure(ids.size()));
+    c->nbTotal = (uint32_t)ids.size();
     VR_HIP(c, hipMemcpyAsync(c->dNodes.p, c->bvh.nodes.data(), c->bvh.nodes.size() * 4, hipMemcpyHostToDevice, c->stream));
     VR_HIP(c, hipMemcpyAsync(c->dPrims.p, prims.data(), prims.size() * 4, hipMemcpyHostToDevice, c->stream));
     VR_HIP(c, hipMemcpyAsync(c->dNbOff.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream));
@@ -668,9 +670,11 @@ static int build_scene(vr_context *c) {
     VR_HIP(c, hipMemcpyAsync(&total, c->dNbOff.p + N, 4, hipMemcpyDeviceToHost, c->stream));
     VR_HIP(c, hipStreamSynchronize(c->stream));
     VR_HIP(c, c->dNbIds.ensure(total));
+    c->nbTotal = total;
     s.nbIds = c->dNbIds.p;
     VR_HIP(c, launch_setup_neighbors(s, 1, c->stream));
   } else {
+    c->nbTotal = 0;
     VR_HIP(c, hipMemsetAsync(c->dNbOff.p, 0, ((size_t)N + 1) * 4, c->stream));
     VR_HIP(c, c->dNbIds.ensure(1));
   }
@@ -704,6 +708,7 @@ static int build_scene(vr_context *c) {
       VR_HIP(c, hipMemcpyAsync(&total, c->dNbOff.p + N, 4, hipMemcpyDeviceToHost, c->stream));
       VR_HIP(c, hipStreamSynchronize(c->stream));
       VR_HIP(c, c->dNbIds.ensure(total));
+      c->nbTotal = total;
       s.nbIds = c->dNbIds.p;
       VR_HIP(c, launch_setup_neighbors(s, 1, c->stream));
       VR_HIP(c, hipStreamSynchronize(c->stream));
@@ -889,12 +894,8 @@ int vr_apply_prepare(vr_context *c) {
   {
     const uint32_t recB = c->geo.geo == 0 ? 32u : 64u;
     uint32_t off[5], o = 0, nbTotal = 0;
-    if (c->geo.geo == 0 && N > 0) {
-      if (c->hostNeighborsValid && !c->geo.nbOff.empty())
-        nbTotal = c->geo.nbOff.back();
-      else
-        VR_HIP(c, hipMemcpy(&nbTotal, c->dNbOff.p + N, 4, hipMemcpyDeviceToHost));
-    }
+    if (c->geo.geo == 0)
+      nbTotal = c->nbTotal;
     auto put = [&](int k, size_t bytes) {
       off[k] = o;
       o += (uint32_t)((bytes + 15) & ~(size_t)15);
