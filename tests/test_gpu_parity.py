@@ -658,6 +658,44 @@ def test_small_scene_kernel_resident_in_lds(geom, sticking, monkeypatch):
     assert i0 == i1 and (f0 == f1).all()
 
 
+@pytest.mark.parametrize("variant", ["coned", "two_label", "material", "wdist", "specular"])
+def test_small_scene_kernel_serves_every_particle(variant, monkeypatch):
+    """MODE 4 with the plug-in particles (extended kernel), two data labels (one accumulator plane each in LDS), the
+    per-material sticking map (staged in LDS) and WDIST crediting: every plane bit-identical to the HBM path."""
+    gd, p, n = trench2d()
+
+    def run():
+        t = vr.TraceDisk(2)
+        t.setGeometry(p, n, gd)
+        t.setSourceDirection(TD.POS_Y)
+        t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 2)
+        if variant == "coned":
+            t.setParticleType(vr.ConedCosineParticle(0.2, 3.0, 0.8, "flux"))
+        elif variant == "two_label":
+            t.setParticleType(vr.DiffuseCosineParticle(0.3, "flux", "cosFlux"))
+        elif variant == "material":
+            t.setMaterialIds((np.arange(len(p)) % 3).astype(np.int32))
+            t.setParticleType(vr.DiffuseParticle(0.2, "flux", materialSticking={1: 0.6, 2: 1.0}))
+        elif variant == "wdist":
+            t.setParticleType(vr.DiffuseParticle(0.25, "flux"))
+            t.setUseWdist(True)
+        else:
+            t.setParticleType(vr.SpecularParticle(0.15, 20.0, "flux"))
+        t.setNumberOfRaysPerPoint(2000)
+        t.setRngSeed(77)
+        t.apply()
+        ld = t.getLocalData()
+        return [np.array(ld.getVectorData(k), copy=True) for k in range(t.numData())], info_dict(t), t.traceMode()
+
+    f1, i1, m1 = run()
+    assert m1 == 4
+    monkeypatch.setenv("VR_SMALL_SCENE", "0")
+    f0, i0, m0 = run()
+    assert m0 != 4 and i0 == i1 and len(f0) == len(f1)
+    for a, b in zip(f0, f1):
+        assert np.array_equal(a, b) and a.sum() > 0
+
+
 # ---------------------------------------------------------------------------
 # edge cases of the reference's loop (limits, degenerate scenes, tiny launches)
 # ---------------------------------------------------------------------------

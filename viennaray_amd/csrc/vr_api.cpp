@@ -888,12 +888,12 @@ int vr_apply_prepare(vr_context *c) {
     c->absorb = false;
   c->kernelParticle = extended ? (int)P_EXT : c->particleKind;
   // a scene of a few hundred primitives goes into LDS as a whole (MODE 4: the general kernel — also for
-  // absorbing particles —, the built-in particles, one data label, no per-material sticking): pair nodes,
-  // records, neighbourhood, accumulators
+  // absorbing particles — of whatever particle): pair nodes, records, neighbourhood, accumulators (one plane
+  // per data label), per-material sticking
   bool smallScene = false;
   {
     const uint32_t recB = c->geo.geo == 0 ? 32u : 64u;
-    uint32_t off[5], o = 0, nbTotal = 0;
+    uint32_t off[6], o = 0, nbTotal = 0;
     if (c->geo.geo == 0)
       nbTotal = c->nbTotal;
     auto put = [&](int k, size_t bytes) {
@@ -904,11 +904,12 @@ int vr_apply_prepare(vr_context *c) {
     put(1, (size_t)N * recB);
     put(2, ((size_t)N + 1) * 4);
     put(3, (size_t)nbTotal * 4);
-    put(4, (size_t)N * 8);
-    smallScene = o <= VR_SMALL_LDS && !extended && !c->havePrimSticking && c->numData == 1 && c->numNodes > 0;
+    put(4, (size_t)N * 8 * c->numData);
+    put(5, c->havePrimSticking ? (size_t)N * 4 : 0);
+    smallScene = o <= VR_SMALL_LDS && c->numNodes > 0;
     if (const char *e = std::getenv("VR_SMALL_SCENE"))
       smallScene = smallScene && std::atoi(e) != 0;
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < 6; ++k)
       p.smallOff[k] = off[k];
     p.smallNb = nbTotal;
     p.smallBytes = (o + 255u) & ~255u;

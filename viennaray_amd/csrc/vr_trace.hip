@@ -437,8 +437,13 @@ trace_kernel(const TraceParams p) {
     for (unsigned k = tid; k < p.smallNb; k += VR_BLOCK)
       li[k] = p.nbIds[k];
     unsigned long long *lf = reinterpret_cast<unsigned long long *>(sceneB + p.smallOff[4]);
-    for (unsigned k = tid; k < p.numPrims; k += VR_BLOCK)
+    for (unsigned k = tid; k < p.numPrims * p.numData; k += VR_BLOCK) // (one plane per data label)
       lf[k] = 0ull;
+    if (p.primSticking) {
+      float *ls = reinterpret_cast<float *>(sceneB + p.smallOff[5]);
+      for (unsigned k = tid; k < p.numPrims; k += VR_BLOCK)
+        ls[k] = p.primSticking[k];
+    }
   }
   __syncthreads();
   unsigned *const cnt = cntS + tid; // counter k of this lane: cnt[k * VR_BLOCK]
@@ -452,6 +457,7 @@ trace_kernel(const TraceParams p) {
                                            : reinterpret_cast<const uint4 *>(p.pnodes);
   const unsigned *__restrict__ nbOff = SMALL ? reinterpret_cast<const unsigned *>(sceneB + p.smallOff[2]) : p.nbOff;
   const unsigned *__restrict__ nbIds = SMALL ? reinterpret_cast<const unsigned *>(sceneB + p.smallOff[3]) : p.nbIds;
+  const float *__restrict__ primSticking = SMALL ? reinterpret_cast<const float *>(sceneB + p.smallOff[5]) : p.primSticking;
   const float4 *__restrict__ rayAB = reinterpret_cast<const float4 *>(p.slotRec);
   unsigned long long *const fluxGlobal = p.fluxAcc + (size_t)(blockIdx.x & p.accMask) * p.accStride; // this block's replica
   unsigned long long *const fluxAcc = SMALL ? reinterpret_cast<unsigned long long *>(sceneB + p.smallOff[4]) : fluxGlobal;
@@ -798,7 +804,7 @@ trace_kernel(const TraceParams p) {
               const int kind = p.particleKind;
               auto creditTo = [&](unsigned q, float w, const V3 &nq) {
                 Particles::collide(kind, w, rayDirection, nq, [&](int label, float v) {
-                  atomicAdd(&fluxAcc[(size_t)label * p.planeStride + q], weight_fx(v));
+                  atomicAdd(&fluxAcc[(size_t)label * (SMALL ? p.numPrims : p.planeStride) + q], weight_fx(v));
                 });
               };
               if (GEO == 0) {
@@ -838,7 +844,7 @@ trace_kernel(const TraceParams p) {
               // the reference makes before that test (Q2) are not observable.
               active = false;
             } else {
-              const float sticking = p.primSticking ? p.primSticking[h.pos] : p.sticking;
+              const float sticking = p.primSticking ? primSticking[h.pos] : p.sticking;
               const float wAfter = rayWeight - rayWeight * sticking;
               if (wAfter <= 0.f) {
                 active = false; // as above: the pending draws die with the ray
@@ -931,9 +937,10 @@ trace_kernel(const TraceParams p) {
   if (SMALL) {
     // every wave of the block has left the loop: the block's LDS accumulators go to its replica in HBM
     __syncthreads();
-    for (unsigned k = tid; k < p.numPrims; k += VR_BLOCK)
-      if (fluxAcc[k])
-        atomicAdd(&fluxGlobal[k], fluxAcc[k]);
+    for (unsigned l = 0; l < p.numData; ++l)
+      for (unsigned k = tid; k < p.numPrims; k += VR_BLOCK)
+        if (fluxAcc[(size_t)l * p.numPrims + k])
+          atomicAdd(&fluxGlobal[(size_t)l * p.planeStride + k], fluxAcc[(size_t)l * p.numPrims + k]);
   }
 #ifdef VR_DIAG
   TICK(7);
@@ -1009,8 +1016,8 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 2>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
     hipLaunchKernelGGL((trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
-  else if (mode == 4 && PARTICLE != P_EXT)
-    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE == P_EXT ? 0 : PARTICLE, 4>), dim3(grid), dim3(VR_BLOCK), p.smallBytes, s, p);
+  else if (mode == 4)
+    hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 4>), dim3(grid), dim3(VR_BLOCK), p.smallBytes, s, p);
   else
     hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   return hipGetLastError();
@@ -1054,8 +1061,8 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode, unsigned smal
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 2>, VR_BLOCK, 0);
   else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>, VR_BLOCK, 0);
-  else if (mode == 4 && PARTICLE != P_EXT)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE == P_EXT ? 0 : PARTICLE, 4>, VR_BLOCK, smallBytes);
+  else if (mode == 4)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 4>, VR_BLOCK, smallBytes);
   else
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 0>, VR_BLOCK, 0);
   return e == hipSuccess ? nb : 2;

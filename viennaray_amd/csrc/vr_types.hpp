@@ -68,8 +68,9 @@ struct TraceParams {
   float nbDist;                        // neighbourhood radius = 2 x disk radius (rayGeometryDisk.hpp:191-192)
   int32_t geoD;                        // dimension of the geometry (2: z does not enter the neighbour test's boxes)
   // MODE 4 (scene resident in LDS): byte offsets of {pair nodes, primitive records, nbOff, nbIds, flux
-  // accumulators} inside the block's VR_SMALL_LDS buffer, and the number of neighbour ids
-  uint32_t smallOff[5], smallNb, smallBytes;
+  // accumulators (numData planes of numPrims), per-primitive sticking} inside the block's dynamic LDS, the number
+  // of neighbour ids and the size of the whole copy
+  uint32_t smallOff[6], smallNb, smallBytes;
   const uint32_t *nbOff;      // [numPrims+1], disk neighbourhood CSR (leaf order)
   const uint32_t *nbIds;      // leaf positions
   const float *primSticking;  // optional [numPrims] (leaf order) or nullptr
