@@ -767,11 +767,19 @@ trace_kernel(const TraceParams p) {
                 // every overlapping neighbour disk is credited the full weight (:271-300)
                 SUB_START
                 const unsigned nb = nbOff[h.pos], ne = nbOff[h.pos + 1];
+                // One dependent access per neighbour instead of three: the next id is fetched while this
+                // neighbour is tested, and both record words are requested together (left to itself the compiler
+                // sinks the centre's load behind the normal's sign test).  Throughput of full launches does not
+                // notice; a launch of 10^6 rays is as long as its longest bounce chain, and this loop was
+                // half of a round's chain of memory latencies.
+                unsigned qNext = nb < ne ? nbIds[nb] : 0u;
                 for (unsigned j = nb; j < ne; ++j) {
                   DIAG(6);
-                  const unsigned q = nbIds[j];
+                  const unsigned q = qNext;
+                  qNext = nbIds[j + 1 < ne ? j + 1 : j];
                   const float4 c4 = prims[2 * q];
                   const float4 n4 = prims[2 * q + 1];
+                  asm volatile("" ::"v"(c4.x), "v"(n4.x)); // (both in flight before the test branches)
                   const bool hitN = local_disc_hit(org, dir, c4, mk(n4.x, n4.y, n4.z)) && !(p.debugFlags & 1u);
                   if (aggregate) {
                     credit_aggregated(fluxAcc, hitN, q, wfx);
