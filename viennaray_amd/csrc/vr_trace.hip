@@ -649,7 +649,7 @@ trace_kernel(const TraceParams p) {
       const unsigned walking = (unsigned)__popcll(ballot64(active && (ORDERED ? node != VR_END : node < p.numNodes)));
       const unsigned minLanes = (!CARRY || exhausted || walking <= p.walkExit) ? 1u : p.walkExit;
       if (ORDERED)
-        pair_walk_lanes<GEO, SD>(p, pnodes, prims, stackS + tid, stackG, active, org, dir, tnear, h, node, sp, minLanes VR_DIAG_PASS);
+        pair_walk_lanes<GEO, SD, MODE != 2>(p, pnodes, prims, stackS + tid, stackG, active, org, dir, tnear, h, node, sp, minLanes VR_DIAG_PASS);
       else
         bvh_walk_lanes<GEO>(p, active, org, dir, tnear, h, node, minLanes VR_DIAG_PASS);
     }
