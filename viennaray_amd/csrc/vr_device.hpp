@@ -570,6 +570,50 @@ template <int SD> __device__ __forceinline__ unsigned walk_pop(const unsigned *s
 // stackS: this lane's column of the LDS stack (entry e at stackS[e * VR_BLOCK]); stackG: this lane's column of
 // the wave's global slab (entry e at stackG[e * 64])
 // pnodes / prims: the pair nodes and primitive records — global memory, or the LDS copies of MODE 4
+// the pending leaves of a wave: every lane tests the primitives of ITS leaf word `pend` (0: none)
+template <int GEO, bool LEAF2>
+__device__ __forceinline__ void walk_leaf_tests(const float4 *__restrict__ prims, const V3 &o, const V3 &d, float invDD,
+                                                float tnear, HitRec &h, unsigned &pend VR_DIAG_ARGS) {
+    if (ballot64(pend != 0u)) {
+      const unsigned first = pend & VR_LEAF_FIRST_MASK;
+      const unsigned cnt = pend ? (pend >> 27) & 15u : 0u;
+      for (unsigned i = 0; ballot64(i < cnt); i += ((GEO == 0 && LEAF2) ? 2u : 1u)) {
+        const bool on = i < cnt;
+#ifdef VR_DIAG
+        if (on) {
+          DIAG(2);
+        }
+#endif
+        const unsigned q = on ? first + i : 0u;
+        float t;
+        if (GEO == 0) {
+          // two disks per pass, all four record words requested together
+          const bool on2 = LEAF2 && i + 1u < cnt;
+          const unsigned q2 = on2 ? q + 1u : q;
+          const float4 c4 = prims[2 * q];
+          const float4 n4 = prims[2 * q + 1];
+          const float4 c5 = prims[2 * q2];
+          const float4 n5 = prims[2 * q2 + 1];
+          asm volatile("" ::"v"(c4.x), "v"(n4.x), "v"(c5.x), "v"(n5.x));
+          if (on && disc_may_hit(o, d, invDD, c4)) {
+            const bool ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
+            hit_update(h, ok, t, __float_as_uint(n4.w), q);
+          }
+          if (on2 && disc_may_hit(o, d, invDD, c5)) {
+            const bool ok = hit_disc(o, d, tnear, c5, mk(n5.x, n5.y, n5.z), t);
+            hit_update(h, ok, t, __float_as_uint(n5.w), q2);
+          }
+        } else {
+          const float4 a = prims[4 * q], b = prims[4 * q + 1], c = prims[4 * q + 2], e = prims[4 * q + 3];
+          const bool ok =
+              hit_tri(o, d, tnear, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(e.x, e.y, e.z), t);
+          hit_update(h, on && ok, t, __float_as_uint(a.w), q);
+        }
+      }
+      pend = 0u;
+    }
+}
+
 // LEAF2: the leaf test takes two disks per pass, all four record words in flight together (8 more live registers:
 // not for the 72-VGPR absorbing kernel)
 template <int GEO, int SD, bool LEAF2 = true>
@@ -660,50 +704,14 @@ __device__ __forceinline__ void pair_walk_lanes(const TraceParams &p, const uint
       }
     }
     TICK(2);
-    if (ballot64(pend != 0u)) {
-      const unsigned first = pend & VR_LEAF_FIRST_MASK;
-      const unsigned cnt = pend ? (pend >> 27) & 15u : 0u;
-      for (unsigned i = 0; ballot64(i < cnt); i += ((GEO == 0 && LEAF2) ? 2u : 1u)) {
-        const bool on = i < cnt;
-#ifdef VR_DIAG
-        if (on) {
-          DIAG(2);
-        }
-#endif
-        const unsigned q = on ? first + i : 0u;
-        float t;
-        if (GEO == 0) {
-          // two disks per pass, all four record words requested together
-          const bool on2 = LEAF2 && i + 1u < cnt;
-          const unsigned q2 = on2 ? q + 1u : q;
-          const float4 c4 = prims[2 * q];
-          const float4 n4 = prims[2 * q + 1];
-          const float4 c5 = prims[2 * q2];
-          const float4 n5 = prims[2 * q2 + 1];
-          asm volatile("" ::"v"(c4.x), "v"(n4.x), "v"(c5.x), "v"(n5.x));
-          if (on && disc_may_hit(o, d, invDD, c4)) {
-            const bool ok = hit_disc(o, d, tnear, c4, mk(n4.x, n4.y, n4.z), t);
-            hit_update(h, ok, t, __float_as_uint(n4.w), q);
-          }
-          if (on2 && disc_may_hit(o, d, invDD, c5)) {
-            const bool ok = hit_disc(o, d, tnear, c5, mk(n5.x, n5.y, n5.z), t);
-            hit_update(h, ok, t, __float_as_uint(n5.w), q2);
-          }
-        } else {
-          const float4 a = prims[4 * q], b = prims[4 * q + 1], c = prims[4 * q + 2], e = prims[4 * q + 3];
-          const bool ok =
-              hit_tri(o, d, tnear, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), mk(e.x, e.y, e.z), t);
-          hit_update(h, on && ok, t, __float_as_uint(a.w), q);
-        }
-      }
-      pend = 0u;
-    }
+    walk_leaf_tests<GEO, LEAF2>(prims, o, d, invDD, tnear, h, pend VR_DIAG_PASS);
     TICK(3);
     if ((unsigned)__popcll(ballot64(node != VR_END)) < minLanes)
       break;
   }
 }
 
+// ---------------------------------------------------------------------------
 // geometry, wave-uniform ("packet"): the 64 rays of a wavefront that were sorted
 // into the same far-plane cell walk the UNION of their paths in lock step.  The
 // node index is a scalar, node and primitive records come through the scalar
