@@ -156,16 +156,56 @@ __device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, 
 // Fixed number of source draws (no tilted primary direction): the NS engine outputs
 // the source sample needs are produced straight into registers by one 156+NS-step pass
 // of the seeding recurrence, which also leaves the streaming cursors for the trace kernel.
+// The bin cursor's returning atomic is the one long latency of a ray; it is issued as soon as the ray's bin is
+// known and its answer is used one loop pass later, after the NEXT ray's seeding chain: the wave computes while
+// its own atomic is under way instead of leaving that to the other waves of the SIMD.
 template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
   constexpr int NS = D == 3 ? 4 : 3;
-  for (unsigned i = blockIdx.x * VR_BLOCK + threadIdx.x; i < p.batchCount; i += gridDim.x * VR_BLOCK) {
-    const unsigned long long idx = p.idxList ? p.idxList[i] : p.batchFirst + i;
-    u64 out[NS], lo, hi;
-    mt_first_outputs<NS>(tea3((unsigned)idx, p.seed), out, lo, hi);
-    int k = 0;
-    V3 o, d;
-    source_sample<D>(p, [&]() { return out[k++]; }, o, d); // k is a compile-time sequence after unrolling
-    gen_store<D, KEEP>(p, i, o, d, (unsigned)NS, lo, hi);
+  const bool binned = p.binCount && !(p.debugFlags & 64u); // flag 64: timing experiment, no binning
+  bool havePrev = false;
+  V3 po = mk(0, 0, 0), pd = mk(0, 0, 1);
+  unsigned pi = 0, pbin = 0, ppos = 0;
+  u64 plo = 0, phi = 0;
+  for (unsigned i = blockIdx.x * VR_BLOCK + threadIdx.x;; i += gridDim.x * VR_BLOCK) {
+    const bool cur = i < p.batchCount;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
+    u64 lo = 0, hi = 0;
+    unsigned b = 0;
+    if (cur) {
+      const unsigned long long idx = p.idxList ? p.idxList[i] : p.batchFirst + i;
+      u64 out[NS];
+      mt_first_outputs<NS>(tea3((unsigned)idx, p.seed), out, lo, hi);
+      int k = 0;
+      source_sample<D>(p, [&]() { return out[k++]; }, o, d); // k is a compile-time sequence after unrolling
+      if (binned)
+        b = bin_of<D>(p, o, project_dir<D>(d));
+    }
+    if (havePrev) { // the previous ray of this lane: its slot has arrived
+      unsigned slot = pi;
+      if (binned) {
+        if (ppos < p.binCap)
+          slot = pbin * p.binCap + ppos;
+        else
+          slot = p.numBins * p.binCap + atomicAdd(&p.binCount[p.numBins], 1u); // < ovCap by construction
+      }
+      // record = {A, B} (32 B) [+ the RNG cursors {s[k], s[k+156]} (16 B) when the particle keeps going]
+      float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + (size_t)(KEEP ? 3 : 2) * slot;
+      rec[0] = make_float4(po.x, po.y, po.z, pd.x);
+      rec[1] = make_float4(pd.y, pd.z, __uint_as_float(pi), __uint_as_float((unsigned)NS));
+      if (KEEP)
+        *reinterpret_cast<ulonglong2 *>(rec + 2) = make_ulonglong2(plo, phi);
+    }
+    if (!cur)
+      break;
+    if (binned)
+      ppos = atomicAdd(&p.binCount[b], 1u); // (answer used in the next pass)
+    po = o;
+    pd = d;
+    pi = i;
+    pbin = b;
+    plo = lo;
+    phi = hi;
+    havePrev = true;
   }
 }
 
