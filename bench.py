@@ -250,8 +250,8 @@ def secondary_case(name, rays, sample, threads, sticking=None, reps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=1000, help="disks per side (C2: 1000)")
     ap.add_argument("--rays", type=int, default=100_000_000, help="primary rays per GPU per step (weak scaling)")
     ap.add_argument("--total-rays", type=int, default=0,
