@@ -33,7 +33,8 @@ struct Tri {       // boundary wall triangle, Embree's precomputed form
 //   k = number of engine outputs the source sampling consumed
 //   +16 B (only for particles that keep going after a hit): C = {s[k], s[k+156]}, the two
 //   cursors of the streaming mt19937_64 (vr_device.hpp, struct Rng)
-constexpr unsigned VR_BIN_CAP = 64; // record slots per sort bin (one wavefront)
+constexpr unsigned VR_BIN_CAP = 128; // record slots per sort bin (4 KB of 32-byte records: the generator's scattered stores
+                                    // and the bin cursors do better with bins a page apart than with 64 slots)
 constexpr int VR_BLOCK = 256;
 // stack of the ordered per-lane walk: the first entries of a lane live in LDS ([entry][lane], 12 in
 // the kernels that walk a lot, 4 in the absorbing flat-scene kernel), deeper ones in a per-wave global slab
