@@ -574,7 +574,9 @@ static int build_scene(vr_context *c) {
 
   // ---- device builder ----
   SetupParams s{};
-  s.leafMax = (uint32_t)VR_LEAF_MAX;
+  // (triangles: a leaf of up to 3 — their test is 64 bytes and ~60 instructions per primitive; measured 4 -> 3:
+  //  trenchMesh 0.1 29.6 -> 28.4 ms, C4 21.4 -> 20.6; disks: 2 .. 4 within 2 %, 6 and 8 slower)
+  s.leafMax = g.geo == 1 ? 3u : (uint32_t)VR_LEAF_MAX;
   if (const char *e = std::getenv("VR_LEAF_MAX"))
     s.leafMax = (uint32_t)std::min(15, std::max(1, std::atoi(e)));
   s.orderAxis = c->ts[0];                   // rays travel along this axis ...
@@ -1276,7 +1278,7 @@ int vr_apply_finish(vr_context *c) {
     unsigned long long dg[32];
     VR_HIP(c, hipMemcpy(dg, c->dCounters.p + 16, sizeof(dg), hipMemcpyDeviceToHost));
     static const char *names[16] = {"rounds", "walk steps", "leaf prim tests", "packet visits", "packet prim tests",
-                                    "state machine", "neighbour iters", "reflect iters", "refill reps", "wall init",
+                                    "state machine", "neighbour iters", "walk steps: unfinished", "refill reps", "wall init",
                                     "roulette", "credit", "pq attempts", "pq done", "visits: no child hit", "visits: both hit"};
     for (int k = 0; k < 16; ++k)
       if (dg[2 * k])

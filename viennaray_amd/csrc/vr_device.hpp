@@ -648,6 +648,9 @@ __device__ __forceinline__ void pair_walk_lanes(const TraceParams &p, const uint
         if (visit) {
           DIAG(1);
         }
+        if (node != VR_END) { // (lanes whose walk is not finished: searching, at a leaf, or parked)
+          DIAG(7);
+        }
 #endif
         const size_t idx = visit ? (size_t)node : 0u;
         const uint4 a = pnodes[2 * idx], b = pnodes[2 * idx + 1];
