@@ -143,14 +143,6 @@ struct vr_context {
   bool hostNeighborsValid = false;
   // ray stream (one batch)
   DevBuf<float> dSlotRec, dSlotRec2, dWalls;
-  // generation-by-generation path (run_batch): two ray queues, the hit records, per-generation counts and the
-  // work counters of its launches
-  DevBuf<float> dQueueA, dQueueB, dHitRec;
-  DevBuf<uint32_t> dWfCount;
-  DevBuf<unsigned long long> dWfWork;
-  bool wavefront = false;
-  unsigned wfGens = 12, wfWalkExit = 40, wfBlocksIsect = 0, wfBlocksShade = 0;
-  uint64_t wfMinRays = 4000000;
   DevBuf<uint32_t> dBinCount, dBinCount2;
   size_t slotStride = 0; // record slots of the ray-stream buffer (bins + overflow region)
   uint32_t raysPerBin = 40;
@@ -1013,36 +1005,9 @@ int vr_apply_prepare(vr_context *c) {
       blocks = std::max(1, std::atoi(e));
     c->grid = (unsigned)c->numCUs * (unsigned)blocks;
   }
-  // generation-by-generation path of the general kernel (run_batch): off unless VR_WAVEFRONT=1
-  c->wavefront = false;
-  if (const char *e = std::getenv("VR_WAVEFRONT"))
-    c->wavefront = std::atoi(e) != 0 && c->traceMode == 0 && !c->overlap;
-  if (c->wavefront) {
-    if (const char *e = std::getenv("VR_WF_GENS"))
-      c->wfGens = (unsigned)std::min(64, std::max(1, std::atoi(e)));
-    if (const char *e = std::getenv("VR_WF_MIN_RAYS"))
-      c->wfMinRays = (uint64_t)std::max<long long>(0, std::atoll(e));
-    if (const char *e = std::getenv("VR_WF_WALK_EXIT"))
-      c->wfWalkExit = (unsigned)std::min(64, std::max(1, std::atoi(e)));
-    c->wfBlocksIsect = (unsigned)std::max(1, trace_stage_blocks_per_cu(D, c->geo.geo, c->kernelParticle, 2));
-    c->wfBlocksShade = (unsigned)std::max(1, trace_stage_blocks_per_cu(D, c->geo.geo, c->kernelParticle, 3));
-    if (const char *e = std::getenv("VR_WF_BLOCKS_ISECT"))
-      c->wfBlocksIsect = (unsigned)std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("VR_WF_BLOCKS_SHADE"))
-      c->wfBlocksShade = (unsigned)std::max(1, std::atoi(e));
-    if (span >= c->wfMinRays) {
-      // (capacity: the rays + the blocks the waves of a stage reserve and do not fill, VR_EMIT_BLOCK = 2048 each)
-      const size_t qcap = (size_t)cap + (size_t)c->numCUs * 8u * (VR_BLOCK / 64) * 2048u;
-      VR_HIP(c, c->dQueueA.ensure(qcap * 16));
-      VR_HIP(c, c->dQueueB.ensure(qcap * 16));
-      VR_HIP(c, c->dHitRec.ensure(qcap * 4));
-      VR_HIP(c, c->dWfCount.ensure(c->wfGens + 4));
-      VR_HIP(c, c->dWfWork.ensure(2 * c->wfGens + 4));
-    }
-  }
   // deep part of the per-lane walk's stack (entries beyond the LDS-resident ones), one slab per resident wave
   {
-    const size_t waves = (size_t)std::max<unsigned>(std::max<unsigned>(c->grid, (unsigned)c->numCUs * 8u), (unsigned)c->numCUs * c->wfBlocksIsect) * (VR_BLOCK / 64);
+    const size_t waves = (size_t)std::max<unsigned>(c->grid, (unsigned)c->numCUs * 8u) * (VR_BLOCK / 64);
     if (waves > c->walkStackWaves) {
       VR_HIP(c, c->dWalkStack.ensure(waves * (size_t)VR_STACK_GLOBAL * 64u));
       c->walkStackWaves = waves;
@@ -1053,7 +1018,7 @@ int vr_apply_prepare(vr_context *c) {
   {
     size_t waves = 0;
     if (!c->absorb)
-      waves = (size_t)std::max<unsigned>(c->grid, c->wavefront ? (unsigned)c->numCUs * std::max(c->wfBlocksShade, 1u) : 0u) * (VR_BLOCK / 64);
+      waves = (size_t)c->grid * (VR_BLOCK / 64);
     if (c->usePrimaryDirection || !c->hostOrg.empty())
       waves = std::max(waves, (size_t)c->numCUs * 8u * (VR_BLOCK / 64)); // launch_gen's grid bound
     if (waves > c->scratchWaves) {
@@ -1265,45 +1230,7 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   // a small batch does not need the whole persistent grid: one wave per 64 rays is plenty
   const unsigned gridBatch =
       (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(c->grid, ((uint64_t)count + 255) / 256));
-  if (c->wavefront && c->traceMode == 0 && count >= c->wfMinRays && c->dQueueA.p) {
-    // generation 0: one segment per (sorted) primary, survivors to queue A.  Generations 1 .. G: closest hits of the
-    // queue's rays (INTERSECT), then the state machine over rays + hits (SHADE), survivors to the other queue.  What
-    // is left after G generations runs to its end in its lanes (RESUME).  The stages hand their ray counts over in
-    // device memory: no host round trip between the launches.
-    const unsigned G = c->wfGens;
-    VR_HIP(c, hipMemsetAsync(c->dWfCount.p, 0, (size_t)(G + 4) * 4, c->stream));
-    VR_HIP(c, hipMemsetAsync(c->dWfWork.p, 0, (size_t)(2 * G + 4) * 8, c->stream));
-    float *Q[2] = {c->dQueueA.p, c->dQueueB.p};
-    TraceParams q = p;
-    q.qCap = (uint32_t)std::min<size_t>((size_t)count + (size_t)c->numCUs * 8u * (VR_BLOCK / 64) * 2048u, 0xFFFFFFFFu);
-    VR_HIP(c, hipMemsetAsync(Q[0], 0, (size_t)q.qCap * 64, c->stream));
-    q.hitBuf = c->dHitRec.p;
-    q.qOut = Q[0];
-    q.qOutCount = c->dWfCount.p + 1;
-    VR_HIP(c, launch_trace_stage(q, c->geo.D, c->geo.geo, c->kernelParticle, 1, gridBatch, c->stream));
-    unsigned w = 0;
-    for (unsigned g = 1; g <= G; ++g) {
-      q.qIn = Q[(g - 1) & 1];
-      q.qInCount = c->dWfCount.p + g;
-      q.qOut = Q[g & 1];
-      q.qOutCount = c->dWfCount.p + g + 1;
-      q.workCounter = c->dWfWork.p + w++;
-      q.walkExit = c->wfWalkExit;
-      VR_HIP(c, launch_trace_stage(q, c->geo.D, c->geo.geo, c->kernelParticle, 2, (unsigned)c->numCUs * c->wfBlocksIsect, c->stream));
-      q.workCounter = c->dWfWork.p + w++;
-      q.walkExit = p.walkExit;
-      VR_HIP(c, hipMemsetAsync(q.qOut, 0, (size_t)q.qCap * 64, c->stream));
-      VR_HIP(c, launch_trace_stage(q, c->geo.D, c->geo.geo, c->kernelParticle, 3, (unsigned)c->numCUs * c->wfBlocksShade, c->stream));
-    }
-    q.qIn = Q[G & 1];
-    q.qInCount = c->dWfCount.p + G + 1;
-    q.qOut = nullptr;
-    q.qOutCount = nullptr;
-    q.workCounter = c->dWfWork.p + w++;
-    VR_HIP(c, launch_trace_stage(q, c->geo.D, c->geo.geo, c->kernelParticle, 4, c->grid, c->stream));
-  } else {
-    VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->kernelParticle, c->traceMode, gridBatch, c->stream));
-  }
+  VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->kernelParticle, c->traceMode, gridBatch, c->stream));
   VR_HIP(c, hipEventRecord(c->evK[2 * batchNo + 1], c->stream));
   if (c->overlap)
     VR_HIP(c, hipEventRecord(c->evTraced[batchNo], c->stream));
@@ -1379,11 +1306,6 @@ int vr_apply_finish(vr_context *c) {
       c->launched = false;
       c->prepared = false;
       return fail(c, VR_E_STATE, "BVH traversal stack overflow (degenerate tree): result discarded");
-    }
-    if (cnt[61]) {
-      c->launched = false;
-      c->prepared = false;
-      return fail(c, VR_E_STATE, "ray queue overflow in the generation-by-generation path: result discarded");
     }
   }
 #ifdef VR_SELFCHECK

@@ -11,9 +11,6 @@ hipError_t launch_gen(const TraceParams &p, int D, bool keepRng, unsigned maxBlo
 hipError_t launch_scan(unsigned *data, unsigned n, unsigned *tmp, hipStream_t s);
 hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int mode, unsigned grid,
                         hipStream_t s);
-// staged kernels of the generation-by-generation path (vr_trace_wf.hip): stage 1 FIRST, 2 INTERSECT, 3 SHADE, 4 RESUME
-hipError_t launch_trace_stage(const TraceParams &p, int D, int geo, int particle, int stage, unsigned grid, hipStream_t s);
-int trace_stage_blocks_per_cu(int D, int geo, int particle, int stage);
 // resident 256-thread blocks per CU of the trace kernel instantiation (occupancy API)
 int trace_blocks_per_cu(int D, int geo, int particle, int mode, unsigned smallBytes);
 hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *org, const float *dir,

@@ -90,16 +90,6 @@ struct TraceParams {
   float eeGrid;
   const float *hostOrg, *hostDir;
   const uint32_t *hostDraws;
-  // generation-by-generation path (staged kernels, vr_trace_kernel.hpp): queues of 64-byte full-state ray records
-  //   {org.xyz, dir.x} {dir.y, dir.z, weight, bits(numReflections)} {RNG cursors lo, hi} {bits(engine seed), bits(k),
-  //   bits(boundaryHits | hitFromBack << 31), -}
-  // and one 16-byte hit record {bits(t), geom, prim, pos} per ray of the input queue
-  const float *qIn;
-  float *qOut;
-  float *hitBuf;
-  const uint32_t *qInCount;  // rays in qIn (device-resident: written by the previous stage)
-  uint32_t *qOutCount;
-  uint32_t qCap;             // capacity of either queue, in records
   unsigned long long *counters;  // [8]
   unsigned long long *workCounter;
   unsigned long long *rngScratch; // [waves][312][64]
