@@ -212,19 +212,19 @@ template <int K> __device__ __forceinline__ void mt_first_outputs(unsigned seed,
   hi = mt_step_v(m, x, 156 + K);
 }
 
-__device__ __noinline__ void rng_tier2_build(Rng &r) {
-  u64 *s = r.scratch;
-  u64 x = r.seed;
+// (The two out-of-line tier-2 routines take the slab and the seed BY VALUE: handed a reference to the engine, the
+//  whole struct had to live in scratch memory — every draw of the streaming tier stored its counter there and the
+//  reflection loop waited on the vector-memory counter once per iteration.)
+__device__ __noinline__ void rng_tier2_build(u64 *s, unsigned seed) {
+  u64 x = seed;
   s[0] = x;
   for (int j = 1; j < 312; ++j) {
     x = mt_step(x, j);
     s[j * 64] = x;
   }
-  r.pos = 312; // forces a twist on first use
 }
 
-__device__ __noinline__ void rng_tier2_twist(Rng &r) {
-  u64 *s = r.scratch;
+__device__ __noinline__ void rng_tier2_twist(u64 *s) {
   u64 cur = s[0];
   for (int i = 0; i < 156; ++i) {
     u64 nxt = s[(i + 1) * 64];
@@ -249,18 +249,18 @@ __device__ __forceinline__ u64 rng_next(Rng &r, unsigned &tier2Count) {
     return v;
   }
   if (r.pos == 0xFFFFFFFFu) {
-    rng_tier2_build(r);
-    rng_tier2_twist(r);
+    rng_tier2_build(r.scratch, r.seed);
+    rng_tier2_twist(r.scratch);
     unsigned skip = r.k; // outputs already consumed by the streaming tier
     while (skip >= 312u) {
-      rng_tier2_twist(r);
+      rng_tier2_twist(r.scratch);
       skip -= 312u;
     }
     r.pos = skip;
     ++tier2Count;
   }
   if (r.pos >= 312u) {
-    rng_tier2_twist(r);
+    rng_tier2_twist(r.scratch);
     r.pos = 0;
   }
   u64 v = mt_temper(r.scratch[r.pos * 64]);
