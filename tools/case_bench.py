@@ -41,6 +41,12 @@ elif case == "plane100":
 else:
     gd, p, n = trench3d()
     t = vr.TraceDisk(3); t.setGeometry(p, n, gd); t.setBoundaryConditions([vr.BoundaryCondition.PERIODIC_BOUNDARY] * 3)
+# VR_CASE_PARTICLE=coned|cosine2: the same workload through the extended kernel (device particle registry)
+_pk = os.environ.get("VR_CASE_PARTICLE", "")
+if _pk == "coned":
+    particle = vr.ConedCosineParticle(sticking, 1.0, 0.8, "flux")
+elif _pk == "cosine2":
+    particle = vr.DiffuseCosineParticle(sticking, "flux", "cosine")
 t.setParticleType(particle if particle is not None else vr.DiffuseParticle(sticking, "flux"))
 if fixed:
     t.setNumberOfRaysFixed(fixed)
