@@ -888,7 +888,8 @@ int vr_apply_prepare(vr_context *c) {
   const bool extended = c->particleKind >= VR_PARTICLE_CONED_COSINE || c->useWdist || c->meanFreePath > 0.f;
   if (extended)
     c->absorb = false;
-  c->kernelParticle = extended ? (int)P_EXT : c->particleKind;
+  // (the coned-cosine model has an instantiation of its own: its double-precision trigonometry costs registers)
+  c->kernelParticle = extended ? (c->particleKind == (int)P_CONED_COSINE ? (int)P_EXT_CONED : (int)P_EXT) : c->particleKind;
   // a scene of a few hundred primitives goes into LDS as a whole (MODE 4: the general kernel — also for
   // absorbing particles — of whatever particle): pair nodes, records, neighbourhood, accumulators (one plane
   // per data label), per-material sticking
@@ -988,10 +989,10 @@ int vr_apply_prepare(vr_context *c) {
     // absorbing particles: a (nearly) flat surface is served by packets alone; a structured one
     // ends most rounds in per-lane walks and wants the straggler carry-over (MODE 2)
     // general particles on a flat surface of disks: the general kernel with the packet query's crediting (MODE 3)
-    c->traceMode = !c->absorb ? ((c->keyShare >= 0.95f && c->geo.geo == 0 && c->kernelParticle != (int)P_EXT) ? 3 : 0)
+    c->traceMode = !c->absorb ? ((c->keyShare >= 0.95f && c->geo.geo == 0 && c->kernelParticle < (int)P_EXT) ? 3 : 0)
                               : (c->keyShare >= 0.95f ? 1 : 2);
     if (const char *e = std::getenv("VR_GENERAL_FLAT"))
-      if (!c->absorb && c->geo.geo == 0 && c->kernelParticle != (int)P_EXT)
+      if (!c->absorb && c->geo.geo == 0 && c->kernelParticle < (int)P_EXT)
         c->traceMode = std::atoi(e) ? 3 : 0;
     if (const char *e = std::getenv("VR_ABSORB_CARRY"))
       if (c->absorb)

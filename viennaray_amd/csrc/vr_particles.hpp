@@ -99,14 +99,15 @@ struct Particles {
   __host__ __device__ static int numData(int kind) { return kind == P_DIFFUSE_COSINE ? 2 : 1; }
 
   // surfaceReflection: new direction (the engine outputs it draws are part of the contract)
-  template <int D>
+  // CONED: the instantiation carries the coned-cosine model (P_EXT_CONED); the host never sends that kind to the other
+  template <int D, bool CONED>
   __device__ __forceinline__ static V3 reflect(int kind, const TraceParams &p, const V3 &rayDir, const V3 &n, Rng &rng,
                                                unsigned &t2) {
-    switch (kind) {
-    case P_SPECULAR: return reflect_specular(rayDir, n);
-    case P_CONED_COSINE: return reflection_coned_cosine<D>(rayDir, n, rng, t2, p.coneAngle);
-    default: return reflection_diffuse<D>(n, rng, t2); // P_DIFFUSE, P_DIFFUSE_COSINE
-    }
+    if (CONED && kind == P_CONED_COSINE)
+      return reflection_coned_cosine<D>(rayDir, n, rng, t2, p.coneAngle);
+    if (kind == P_SPECULAR)
+      return reflect_specular(rayDir, n);
+    return reflection_diffuse<D>(n, rng, t2); // P_DIFFUSE, P_DIFFUSE_COSINE
   }
 
   // surfaceCollision: `credit(label, value)` adds to this primitive's entry of a data label

@@ -424,7 +424,7 @@ trace_kernel(const TraceParams p) {
   // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
   // extended kernel — particle kind, data labels, WDIST crediting and mean-free-path scattering
   // decided at run time from TraceParams (vr_particles.hpp)
-  constexpr bool EXT = PARTICLE == P_EXT;
+  constexpr bool EXT = PARTICLE >= P_EXT; // (P_EXT, P_EXT_CONED)
   // packet-query rounds credit disks wave-uniformly from the candidate list (pq_credit) instead of
   // walking the neighbour CSR per lane
   constexpr bool PQ_CREDIT = GEO == 0 && !EXT && (MODE == 1 || MODE == 3);
@@ -875,12 +875,18 @@ trace_kernel(const TraceParams p) {
                   }
                 }
                 creditTo(h.pos, p.useWdist ? rayWeight / dClosest / invSum * (float)numHit : rayWeight, geomNormal);
+                // (as in the built-in particles' loop: the next id is fetched while this neighbour is tested, and both
+                //  record words are requested together — one dependent access per neighbour instead of three)
+                unsigned qNext = nb < ne ? nbIds[nb] : 0u;
                 for (unsigned j = nb; j < ne; ++j) {
-                  const unsigned q = nbIds[j];
+                  const unsigned q = qNext;
+                  qNext = nbIds[j + 1 < ne ? j + 1 : j];
+                  const float4 c4 = prims[2 * q];
                   const float4 n4 = prims[2 * q + 1];
+                  asm volatile("" ::"v"(c4.x), "v"(n4.x));
                   const V3 nq = mk(n4.x, n4.y, n4.z);
                   float dist;
-                  if (local_disc_hit_dist(org, dir, prims[2 * q], nq, dist))
+                  if (local_disc_hit_dist(org, dir, c4, nq, dist))
                     creditTo(q, p.useWdist ? rayWeight / (dist + 1e-6f) / invSum * (float)numHit : rayWeight, nq);
                 }
               } else {
@@ -905,7 +911,7 @@ trace_kernel(const TraceParams p) {
                 else if (PARTICLE == 1)
                   newDir = reflect_specular(rayDirection, geomNormal);
                 else
-                  newDir = Particles::reflect<D>(p.particleKind, p, rayDirection, geomNormal, rng, cnt[K_TIER2 * VR_BLOCK]);
+                  newDir = Particles::reflect<D, PARTICLE == P_EXT_CONED>(p.particleKind, p, rayDirection, geomNormal, rng, cnt[K_TIER2 * VR_BLOCK]);
                 rayWeight = wAfter;
                 if (++numReflections > p.maxReflections) { // :320-324
                   VR_COUNT(K_TERM, 1);
@@ -1062,8 +1068,8 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 1>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 2)
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 2>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
-  else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
-    hipLaunchKernelGGL((trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  else if (mode == 3 && GEO == 0 && PARTICLE < P_EXT)
+    hipLaunchKernelGGL((trace_kernel<D, 0, PARTICLE >= P_EXT ? 0 : PARTICLE, 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 4)
     hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 4>), dim3(grid), dim3(VR_BLOCK), p.smallBytes, s, p);
   else
@@ -1072,23 +1078,20 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
 }
 
 // mode: 0 general, 1 absorbing + flat scene, 2 absorbing + structured scene
-// particle: 0 DiffuseParticle, 1 SpecularParticle, 2 (P_EXT) extended kernel (always mode 0)
+// particle: 0 DiffuseParticle, 1 SpecularParticle, 2 (P_EXT) extended kernel, 3 (P_EXT_CONED) ... with the coned-cosine
+// model (always mode 0 or 4)
 template <class F> static auto dispatch_variant(int D, int geo, int particle, F &&f) {
-  const int key = (D == 2 ? 0 : 6) + (geo ? 3 : 0) + particle;
+  const int key = (D == 2 ? 0 : 8) + (geo ? 4 : 0) + particle;
+#define VR_VARIANT(K, DD, GG, PP)                                                                                      \
+  case K: return f(std::integral_constant<int, DD>{}, std::integral_constant<int, GG>{}, std::integral_constant<int, PP>{});
   switch (key) {
-  case 0: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-  case 1: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-  case 2: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-  case 3: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-  case 4: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-  case 5: return f(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
-  case 6: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-  case 7: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-  case 8: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-  case 9: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-  case 10: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-  default: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    VR_VARIANT(0, 2, 0, 0) VR_VARIANT(1, 2, 0, 1) VR_VARIANT(2, 2, 0, 2) VR_VARIANT(3, 2, 0, 3)
+    VR_VARIANT(4, 2, 1, 0) VR_VARIANT(5, 2, 1, 1) VR_VARIANT(6, 2, 1, 2) VR_VARIANT(7, 2, 1, 3)
+    VR_VARIANT(8, 3, 0, 0) VR_VARIANT(9, 3, 0, 1) VR_VARIANT(10, 3, 0, 2) VR_VARIANT(11, 3, 0, 3)
+    VR_VARIANT(12, 3, 1, 0) VR_VARIANT(13, 3, 1, 1) VR_VARIANT(14, 3, 1, 2)
+  default: return f(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
   }
+#undef VR_VARIANT
 }
 
 hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int mode, unsigned grid,
@@ -1107,8 +1110,8 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode, unsigned smal
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 1>, VR_BLOCK, 0);
   else if (mode == 2)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 2>, VR_BLOCK, 0);
-  else if (mode == 3 && GEO == 0 && PARTICLE != P_EXT)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, PARTICLE == P_EXT ? 0 : PARTICLE, 3>, VR_BLOCK, 0);
+  else if (mode == 3 && GEO == 0 && PARTICLE < P_EXT)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, PARTICLE >= P_EXT ? 0 : PARTICLE, 3>, VR_BLOCK, 0);
   else if (mode == 4)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 4>, VR_BLOCK, smallBytes);
   else

@@ -162,7 +162,9 @@ struct SetupParams {
 };
 
 // particle kinds of the device registry (include/viennaray_amd.h: VR_PARTICLE_*)
-enum { P_DIFFUSE = 0, P_SPECULAR = 1, P_CONED_COSINE = 2, P_DIFFUSE_COSINE = 3, P_EXT = 2 /* template id of the extended kernel */ };
+enum { P_DIFFUSE = 0, P_SPECULAR = 1, P_CONED_COSINE = 2, P_DIFFUSE_COSINE = 3, P_EXT = 2 /* template id of the extended kernel */,
+       P_EXT_CONED = 3 /* ... with the coned-cosine model compiled in (its double-precision sin / cos cost every
+                          model of the instantiation registers: 157 spilled VGPRs against 54) */ };
 
 // counters[] slots
 enum {
