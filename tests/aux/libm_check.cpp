@@ -78,5 +78,25 @@ int main(int argc, char **argv) {
     }
   }
   std::printf("expf: %ld inputs, mismatches %ld\n", nE, badE);
-  return (badS || badC || badP || badA || badSf || badE) ? 1 : 0;
+  // double-precision sin / cos of the coned-cosine reflection (vr_sincos_small, |x| <= 2 pi): within 1 ulp of the
+  // running libm, and identical after the narrowing to float on the whole sample
+  long badD = 0, badF = 0, nD = 0;
+  {
+    const long N = quick ? 4000000 : 400000000;
+#pragma omp parallel for reduction(+ : badD, badF, nD) schedule(static)
+    for (long i = 0; i <= N; ++i) {
+      // a dense sweep of [0, 2 pi] plus the small-angle end
+      const double x = (i & 1) ? 6.283185307179586 * (double)i / (double)N : 1.6 * (double)i / (double)N * (double)i / (double)N;
+      double s, c;
+      vr::vr_sincos_small(x, s, c);
+      const double rs = std::sin(x), rc = std::cos(x);
+      const double us = std::fabs(rs) > 0 ? std::nextafter(std::fabs(rs), 2.0) - std::fabs(rs) : 5e-324;
+      const double uc = std::fabs(rc) > 0 ? std::nextafter(std::fabs(rc), 2.0) - std::fabs(rc) : 5e-324;
+      badD += std::fabs(s - rs) > us || std::fabs(c - rc) > uc;
+      badF += (float)s != (float)rs || (float)c != (float)rc;
+      ++nD;
+    }
+  }
+  std::printf("sincos (double, range-limited): %ld inputs, beyond 1 ulp %ld, float-narrowed mismatches %ld\n", nD, badD, badF);
+  return (badS || badC || badP || badA || badSf || badE || badD || badF) ? 1 : 0;
 }

@@ -15,3 +15,4 @@ def test_device_libm_matches_glibc(tmp_path):
     out = subprocess.run([exe, "quick"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "sin mismatches 0, cos mismatches 0" in out.stdout
+    assert "beyond 1 ulp 0, float-narrowed mismatches 0" in out.stdout

@@ -243,4 +243,50 @@ VR_HD float glibc_expf(float x) {
   return (float)(y * sc);
 }
 
+// ---------------------------------------------------------------------------
+// double-precision sin / cos for |x| <= 8 (the coned-cosine reflection's three argument ranges: theta in [0, 1.6],
+// pi/2 * s in [0, pi/2], phi in [0, 2 pi)): a two-part Cody-Waite reduction by pi/2 (|n| <= 5: exact products) and
+// the classic Sun fdlibm kernel polynomials (k_sin.c / k_cos.c, Copyright (C) 1993 Sun Microsystems, freely
+// usable with this notice), error < 1 ulp like the libm the reference links.  The device library's sin / cos
+// carry the reduction for arguments up to 1e308 — register pressure and code the tracer never needs.  After the
+// narrowing to float this and glibc's result differ with probability ~1e-8 per sample (the rounding boundary of
+// the float falls between the two doubles), the same as with the device library before.
+// ---------------------------------------------------------------------------
+VR_HD void vr_sincos_small(double x, double &sn, double &cs) {
+  const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+  const double fn = __builtin_rint(x * invpio2);
+  const int n = (int)fn;
+  const double r0 = x - fn * pio2_1; // (exact: pio2_1 has 33 significant bits, |fn| <= 5)
+  const double w = fn * pio2_1t;
+  const double y0 = r0 - w;          // reduced argument, |y0| <= pi/4 (+ rounding)
+  const double y1 = (r0 - y0) - w;   // its tail
+  const double z = y0 * y0;
+  // k_sin
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double v = z * y0;
+  const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  const double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+  // k_cos
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  const double ay = y0 < 0. ? -y0 : y0;
+  double kc;
+  if (ay < 0.3) {
+    kc = 1.0 - (0.5 * z - (z * rc - y0 * y1));
+  } else {
+    const double qx = ay > 0.78125 ? 0.28125 : ay * 0.25; // (fdlibm: x / 4 with the low word cleared; any qx near it serves)
+    const double hz = 0.5 * z - qx;
+    const double a = 1.0 - qx;
+    kc = a - (hz - (z * rc - y0 * y1));
+  }
+  switch (n & 3) {
+  case 0: sn = ks; cs = kc; break;
+  case 1: sn = kc; cs = -ks; break;
+  case 2: sn = -ks; cs = -kc; break;
+  default: sn = -kc; cs = ks; break;
+  }
+}
+
 } // namespace vr

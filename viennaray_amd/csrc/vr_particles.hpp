@@ -47,8 +47,8 @@ template <int D> __device__ __forceinline__ V3 reflection_diffuse(const V3 &n, R
 }
 
 // rayReflection.hpp:52-120.  The accept-reject loop and the trigonometry run in double like the
-// reference; sin / cos are the device library's (not glibc's bit for bit: after the narrowing
-// to float the two differ with probability ~1e-8 per sample).
+// reference; sin / cos are vr_libm.hpp's range-limited pair (< 1 ulp, not glibc's bit for bit: after the
+// narrowing to float the two can differ with probability ~1e-8 per sample).
 template <int D>
 __device__ __forceinline__ V3 reflection_coned_cosine(const V3 &rayDir, const V3 &n, Rng &rng, unsigned &t2,
                                                       float maxConeAngle) {
@@ -68,19 +68,26 @@ __device__ __forceinline__ V3 reflection_coned_cosine(const V3 &rayDir, const V3
     t = mk(1.f - w.x * w.x * a, bx, -w.x);
     b = mk(bx, by, -w.y);
   }
-  double theta;
+  // (sin / cos: the range-limited pair of vr_libm.hpp — theta <= 1.6, pi/2 s <= pi/2, phi < 2 pi — three
+  //  evaluations per reflection instead of six calls of the device library's full-range routines)
+  double theta, sinTheta, cosTheta;
   for (;;) {
     const double u = sqrt(canon_f64(rng_next(rng, t2)));
     const double s = sqrt(fmax(1.0 - u, 0.0));
     theta = (double)maxConeAngle * s;
-    const double rhs = cos(1.57079632679489661923 * s) * sin(theta);
+    double sinHalf, cosHalf;
+    vr_sincos_small(1.57079632679489661923 * s, sinHalf, cosHalf);
+    vr_sincos_small(theta, sinTheta, cosTheta);
+    const double rhs = cosHalf * sinTheta;
     if (canon_f64(rng_next(rng, t2)) * theta * u <= rhs)
       break;
   }
-  const float sinT = (float)sin(theta);
-  const float cosT = (float)cos(theta);
+  const float sinT = (float)sinTheta;
+  const float cosT = (float)cosTheta;
   const double phi = 2.0 * 3.14159265358979323846 * canon_f64(rng_next(rng, t2));
-  const float sinP = (float)sin(phi), cosP = (float)cos(phi);
+  double sinPhi, cosPhi;
+  vr_sincos_small(phi, sinPhi, cosPhi);
+  const float sinP = (float)sinPhi, cosP = (float)cosPhi;
   V3 dir = mk(sinT * (cosP * t.x + sinP * b.x) + cosT * w.x, sinT * (cosP * t.y + sinP * b.y) + cosT * w.y,
               sinT * (cosP * t.z + sinP * b.z) + cosT * w.z);
   const float dp = vdot(dir, n);
