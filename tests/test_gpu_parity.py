@@ -446,6 +446,7 @@ def test_gpu_shard_driver_matches_plain_apply():
         acc, c = shard.trace_local(first, count, run_number=1)
         torch.cuda.synchronize()
         total += acc
+        c = np.asarray(c.tolist() if hasattr(c, "tolist") else c, dtype=np.int64)
         cnt = c if cnt is None else cnt + c
     assert (vd.accumulators_to_flux(total) == ref).all()
     gi = info_dict(t)

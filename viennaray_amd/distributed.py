@@ -67,7 +67,7 @@ class GpuShard:
             info = None
             cnt = [0] * len(COUNTER_KEYS)
         self.last_info = info
-        return self.acc, torch.tensor(cnt, dtype=torch.int64, device=self.device)
+        return self.acc, cnt
 
 
 def distributed_apply(shard, num_rays, rank=None, world=None, group=None, run_number=None):
@@ -81,9 +81,16 @@ def distributed_apply(shard, num_rays, rank=None, world=None, group=None, run_nu
     first, count = ray_shard(num_rays, rank, world)
     acc, cnt = shard.trace_local(first, count, run_number)
     if world > 1:
+        import torch
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # exact: integers
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
-    counters = {k: int(v) for k, v in zip(COUNTER_KEYS, cnt.tolist())}
+        # (the counters travel as a device tensor only when there is something to reduce: a single rank keeps
+        #  them on the host and saves two trips over PCIe per apply)
+        cnt_t = cnt if torch.is_tensor(cnt) else torch.tensor(cnt, dtype=torch.int64, device=acc.device)
+        dist.all_reduce(cnt_t, op=dist.ReduceOp.SUM, group=group)
+        cnt = cnt_t
+    if hasattr(cnt, "tolist"):
+        cnt = cnt.tolist()
+    counters = {k: int(v) for k, v in zip(COUNTER_KEYS, cnt)}
     counters["numRays"] = int(num_rays)
     return acc, counters
 
