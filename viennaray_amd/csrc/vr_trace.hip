@@ -510,7 +510,14 @@ trace_kernel(const TraceParams p) {
   V3 org = mk(0, 0, 0), rayDirection = mk(0, 0, 1), dir2 = mk(0, 0, 1);
   V3 &dir = D == 3 ? rayDirection : dir2;
   float rayWeight = 0.f;
-  unsigned numReflections = 0, boundaryHits = 0;
+  // The two per-ray counters are touched once per segment: in the general kernels they live in LDS, not in two of
+  // the 80 VGPRs (left to the register allocator they went to scratch, and a scratch reload waits on the
+  // vector-memory counter: for every load and atomic the wave has in flight).
+  constexpr bool COLD_IN_LDS = !ABSORB && !SMALL;
+  __shared__ unsigned coldS[COLD_IN_LDS ? 2 * VR_BLOCK : 1];
+  unsigned numReflectionsR = 0, boundaryHitsR = 0;
+  unsigned &numReflections = COLD_IN_LDS ? coldS[tid] : numReflectionsR;
+  unsigned &boundaryHits = COLD_IN_LDS ? coldS[VR_BLOCK + tid] : boundaryHitsR;
   bool hitFromBack = false;
   bool start = false; // this lane begins a new trace segment in this round
   unsigned node = VR_END; // cursor of the lane's BVH walk (VR_END: none under way)
