@@ -888,8 +888,10 @@ int vr_apply_prepare(vr_context *c) {
   const bool extended = c->particleKind >= VR_PARTICLE_CONED_COSINE || c->useWdist || c->meanFreePath > 0.f;
   if (extended)
     c->absorb = false;
-  // (the coned-cosine model has an instantiation of its own: its double-precision trigonometry costs registers)
-  c->kernelParticle = extended ? (c->particleKind == (int)P_CONED_COSINE ? (int)P_EXT_CONED : (int)P_EXT) : c->particleKind;
+  // (the rare, register-hungry options — coned-cosine model, WDIST crediting, mean free path — have an instantiation
+  //  of their own: multi-label and per-material particles should not pay for them)
+  const bool extFull = c->particleKind == (int)P_CONED_COSINE || c->useWdist || c->meanFreePath > 0.f;
+  c->kernelParticle = extended ? (extFull ? (int)P_EXT_FULL : (int)P_EXT) : c->particleKind;
   // a scene of a few hundred primitives goes into LDS as a whole (MODE 4: the general kernel — also for
   // absorbing particles — of whatever particle): pair nodes, records, neighbourhood, accumulators (one plane
   // per data label), per-material sticking

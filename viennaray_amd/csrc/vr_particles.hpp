@@ -106,7 +106,7 @@ struct Particles {
   __host__ __device__ static int numData(int kind) { return kind == P_DIFFUSE_COSINE ? 2 : 1; }
 
   // surfaceReflection: new direction (the engine outputs it draws are part of the contract)
-  // CONED: the instantiation carries the coned-cosine model (P_EXT_CONED); the host never sends that kind to the other
+  // CONED: the instantiation carries the coned-cosine model (P_EXT_FULL); the host never sends that kind to the other
   template <int D, bool CONED>
   __device__ __forceinline__ static V3 reflect(int kind, const TraceParams &p, const V3 &rayDir, const V3 &n, Rng &rng,
                                                unsigned &t2) {

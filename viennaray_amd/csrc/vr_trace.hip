@@ -424,7 +424,8 @@ trace_kernel(const TraceParams p) {
   // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
   // extended kernel — particle kind, data labels, WDIST crediting and mean-free-path scattering
   // decided at run time from TraceParams (vr_particles.hpp)
-  constexpr bool EXT = PARTICLE >= P_EXT; // (P_EXT, P_EXT_CONED)
+  constexpr bool EXT = PARTICLE >= P_EXT;           // (P_EXT, P_EXT_FULL)
+  constexpr bool EXT_FULL = PARTICLE == P_EXT_FULL; // ... with the coned-cosine model, WDIST crediting and the mean free path
   // packet-query rounds credit disks wave-uniformly from the candidate list (pq_credit) instead of
   // walking the neighbour CSR per lane
   constexpr bool PQ_CREDIT = GEO == 0 && !EXT && (MODE == 1 || MODE == 3);
@@ -751,7 +752,7 @@ trace_kernel(const TraceParams p) {
       } else {
         const V3 hitPoint = mk(org.x + dir.x * h.t, org.y + dir.y * h.t, org.z + dir.z * h.t);
         bool scattered = false;
-        if (EXT && p.meanFreePath > 0.f) {
+        if (EXT && EXT_FULL && p.meanFreePath > 0.f) {
           // mean-free-path scatter (rayTraceKernel.hpp:179-203), quirk Q1 kept: tested after the
           // closest hit was found, and the origin moves by dir * rnd (the uniform number itself)
           const float rnd = canon_f32(rng_next(rng, cnt[K_TIER2 * VR_BLOCK]));
@@ -866,7 +867,7 @@ trace_kernel(const TraceParams p) {
                 const unsigned nb = nbOff[h.pos], ne = nbOff[h.pos + 1];
                 float invSum = 0.f, dClosest = 0.f;
                 unsigned numHit = 1;
-                if (p.useWdist) {
+                if (EXT_FULL && p.useWdist) {
                   const float4 cp = prims[2 * h.pos];
                   const V3 dv = mk(hitPoint.x - cp.x, hitPoint.y - cp.y, hitPoint.z - cp.z);
                   dClosest = sqrtf(vdot(dv, dv)) + 1e-6f;
@@ -881,7 +882,7 @@ trace_kernel(const TraceParams p) {
                     }
                   }
                 }
-                creditTo(h.pos, p.useWdist ? rayWeight / dClosest / invSum * (float)numHit : rayWeight, geomNormal);
+                creditTo(h.pos, (EXT_FULL && p.useWdist) ? rayWeight / dClosest / invSum * (float)numHit : rayWeight, geomNormal);
                 // (as in the built-in particles' loop: the next id is fetched while this neighbour is tested, and both
                 //  record words are requested together — one dependent access per neighbour instead of three)
                 unsigned qNext = nb < ne ? nbIds[nb] : 0u;
@@ -894,7 +895,7 @@ trace_kernel(const TraceParams p) {
                   const V3 nq = mk(n4.x, n4.y, n4.z);
                   float dist;
                   if (local_disc_hit_dist(org, dir, c4, nq, dist))
-                    creditTo(q, p.useWdist ? rayWeight / (dist + 1e-6f) / invSum * (float)numHit : rayWeight, nq);
+                    creditTo(q, (EXT_FULL && p.useWdist) ? rayWeight / (dist + 1e-6f) / invSum * (float)numHit : rayWeight, nq);
                 }
               } else {
                 creditTo(h.pos, rayWeight, geomNormal);
@@ -918,7 +919,7 @@ trace_kernel(const TraceParams p) {
                 else if (PARTICLE == 1)
                   newDir = reflect_specular(rayDirection, geomNormal);
                 else
-                  newDir = Particles::reflect<D, PARTICLE == P_EXT_CONED>(p.particleKind, p, rayDirection, geomNormal, rng, cnt[K_TIER2 * VR_BLOCK]);
+                  newDir = Particles::reflect<D, EXT_FULL>(p.particleKind, p, rayDirection, geomNormal, rng, cnt[K_TIER2 * VR_BLOCK]);
                 rayWeight = wAfter;
                 if (++numReflections > p.maxReflections) { // :320-324
                   VR_COUNT(K_TERM, 1);
@@ -1085,8 +1086,8 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
 }
 
 // mode: 0 general, 1 absorbing + flat scene, 2 absorbing + structured scene
-// particle: 0 DiffuseParticle, 1 SpecularParticle, 2 (P_EXT) extended kernel, 3 (P_EXT_CONED) ... with the coned-cosine
-// model (always mode 0 or 4)
+// particle: 0 DiffuseParticle, 1 SpecularParticle, 2 (P_EXT) extended kernel, 3 (P_EXT_FULL) ... with the coned-cosine
+// model, WDIST crediting and mean-free-path scattering (always mode 0 or 4)
 template <class F> static auto dispatch_variant(int D, int geo, int particle, F &&f) {
   const int key = (D == 2 ? 0 : 8) + (geo ? 4 : 0) + particle;
 #define VR_VARIANT(K, DD, GG, PP)                                                                                      \

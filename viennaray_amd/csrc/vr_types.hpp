@@ -163,8 +163,9 @@ struct SetupParams {
 
 // particle kinds of the device registry (include/viennaray_amd.h: VR_PARTICLE_*)
 enum { P_DIFFUSE = 0, P_SPECULAR = 1, P_CONED_COSINE = 2, P_DIFFUSE_COSINE = 3, P_EXT = 2 /* template id of the extended kernel */,
-       P_EXT_CONED = 3 /* ... with the coned-cosine model compiled in (its double-precision sin / cos cost every
-                          model of the instantiation registers: 157 spilled VGPRs against 54) */ };
+       P_EXT_FULL = 3 /* ... with the coned-cosine model, WDIST crediting and mean-free-path scattering compiled in
+                         (rare options that cost every particle of the instantiation registers: 157 spilled VGPRs
+                         with them, 27 without) */ };
 
 // counters[] slots
 enum {
