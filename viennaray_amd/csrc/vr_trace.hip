@@ -858,9 +858,15 @@ trace_kernel(const TraceParams p) {
               // labels receive; with WDIST the weight is shared by inverse impact distance
               // (rayTraceKernel.hpp:258-296: w / d_i / sum(1/d) * numDisksHit, closest disk first)
               const int kind = p.particleKind;
+              // (a coarse scene under sorted rays: a good share of the wave credits ONE disk — merged per distinct
+              //  weight like the built-in particles' credits, or the 64 lanes queue up on one address in L2)
               auto creditTo = [&](unsigned q, float w, const V3 &nq) {
                 Particles::collide(kind, w, rayDirection, nq, [&](int label, float v) {
-                  atomicAdd(&fluxAcc[(size_t)label * (SMALL ? p.numPrims : p.planeStride) + q], weight_fx(v));
+                  unsigned long long *plane = fluxAcc + (size_t)label * (SMALL ? p.numPrims : p.planeStride);
+                  if (aggregate && !SMALL) // (LDS accumulators take 64 adds on one address in their stride)
+                    credit_aggregated(plane, true, q, weight_fx(v));
+                  else
+                    atomicAdd(&plane[q], weight_fx(v));
                 });
               };
               if (GEO == 0) {
