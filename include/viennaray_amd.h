@@ -71,6 +71,10 @@ typedef struct vr_trace_info {
   uint64_t rngFullStates; /* diagnostic: rays that drew more than 156 numbers and continued
                              on the full 312-word engine state       */
   double timeGenKernel;   /* seconds: the ray generator kernel(s) alone (HIP events)  */
+  uint32_t bvhRefits;     /* diagnostic: 1 if the resident BVH failed its first consistency check and was
+                             re-fitted with agent-scope fences (expected 0; non-zero is a finding, not a
+                             state to live with: the tests and smoke() assert 0)               */
+  uint32_t bvhBuilds;     /* scene builds this context has run so far (a re-apply on unchanged geometry adds none) */
 } vr_trace_info;
 
 /* gpu::Particle-style POD (rayParticle.hpp:208-218): a built-in particle.
@@ -122,6 +126,12 @@ int vr_set_source_grid(vr_context *ctx, const float *points3, uint32_t n);
 /* setSource(any other Source) (raySource.hpp:10-19): the facade runs the callback on the host and
  * hands over ray idx -> origin, direction, engine outputs consumed.  n == 0 = resetSource()      */
 int vr_set_host_rays(vr_context *ctx, const float *org3, const float *dir3, const uint32_t *draws, uint64_t n);
+/* Source::getInitialRayWeight(idx) (raySource.hpp:18; rayTraceKernel.hpp:124,316-328,435-460) of the rays given
+ * with vr_set_host_rays: start weight of ray idx and scale of the roulette's thresholds.  n == 0: all 1          */
+int vr_set_host_ray_weights(vr_context *ctx, const float *weights, uint64_t n);
+/* Source::getSourceArea() (raySource.hpp:17) for normalizeFlux(SOURCE) (rayTraceDisk.hpp:127,
+ * rayTraceTriangle.hpp:113); area <= 0: SourceRandom's (raySourceRandom.hpp:40-47, the bbox source face)       */
+int vr_set_source_area(vr_context *ctx, float area);
 int vr_set_number_of_rays_per_point(vr_context *ctx, uint64_t n);
 int vr_set_number_of_rays_fixed(vr_context *ctx, uint64_t n);
 int vr_set_max_reflections(vr_context *ctx, uint32_t n);
@@ -137,6 +147,11 @@ int vr_get_run_number(const vr_context *ctx, uint32_t *runNumber);
  * stays global, so the union over ranks reproduces the single-device stream
  * (rayTraceKernel.hpp:118-121).                                             */
 int vr_set_ray_range(vr_context *ctx, uint64_t first, uint64_t count);
+
+/* Not in the reference (its ray loop allocates nothing per apply): apply() once per time step with a ray
+ * count that follows the moving surface re-sizes the HBM ray stream; reserve it for the largest count
+ * expected.  (Without a reservation the stream grows by half again when it must, and is kept.)             */
+int vr_reserve_rays(vr_context *ctx, uint64_t n);
 
 /* ---- run (Trace::apply) -------------------------------------------------- */
 int vr_apply(vr_context *ctx);

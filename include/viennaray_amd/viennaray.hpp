@@ -44,6 +44,12 @@
 #include <utility>
 #include <vector>
 
+// (the reference's headers pull in OpenMP: programs written against them call omp_set_num_threads() without
+//  including <omp.h> themselves — tests/traceInterface/traceInterface.cpp:27, tests/rngSeed/rngSeed.cpp:10)
+#if defined(_OPENMP) && __has_include(<omp.h>)
+#include <omp.h>
+#endif
+
 #include "../viennaray_amd.h"
 
 namespace viennacore {
@@ -96,6 +102,13 @@ template <class T, size_t D> void Normalize(VectorType<T, D> &a) {
     for (size_t i = 0; i < D; ++i)
       a[i] /= n;
 }
+// (ViennaCore has both forms: in place for an lvalue, a normalised copy for a const / temporary argument —
+//  tests/smoothing/smoothing.cpp:26 uses the second)
+template <class T, size_t D> VectorType<T, D> Normalize(const VectorType<T, D> &a) {
+  VectorType<T, D> r = a;
+  Normalize(r);
+  return r;
+}
 template <class T, size_t D> bool IsNormalized(const VectorType<T, D> &a) {
   return std::fabs(Norm(a) - T(1)) < T(1e-4);
 }
@@ -106,6 +119,49 @@ VectorType<T, D> ScaleAdd(const VectorType<T, D> &a, const VectorType<T, D> &b, 
   return f * a + b;
 }
 template <class T> Vec3D<T> ComputeNormal(const Vec3D<Vec3D<T>> &p) { return CrossProduct(p[1] - p[0], p[2] - p[0]); }
+
+// vcLogger.hpp: the part ViennaRay programs touch (examples/triangle3D/triangle3D.cpp:14:
+// Logger::setLogLevel(LogLevel::DEBUG)).  Messages at or below the current level go to std::cout / std::cerr;
+// nothing here aborts.
+enum class LogLevel : unsigned { ERROR = 0, WARNING = 1, INFO = 2, INTERMEDIATE = 3, TIMING = 4, DEBUG = 5 };
+class Logger {
+  std::string pending_;
+  bool toError_ = false;
+  static LogLevel &level() {
+    static LogLevel l = LogLevel::INFO;
+    return l;
+  }
+  Logger() = default;
+  Logger &add(LogLevel l, const char *tag, const std::string &msg, bool err) {
+    if (static_cast<unsigned>(level()) >= static_cast<unsigned>(l)) {
+      pending_ += std::string("\n    ") + tag + msg + "\n";
+      toError_ = toError_ || err;
+    }
+    return *this;
+  }
+
+public:
+  Logger(const Logger &) = delete;
+  Logger &operator=(const Logger &) = delete;
+  static Logger &getInstance() {
+    static Logger instance;
+    return instance;
+  }
+  static void setLogLevel(LogLevel l) { level() = l; }
+  static LogLevel getLogLevel() { return level(); }
+  Logger &addDebug(const std::string &s) { return add(LogLevel::DEBUG, "DEBUG: ", s, false); }
+  Logger &addTiming(const std::string &s, double seconds) {
+    return add(LogLevel::TIMING, "", s + ": " + std::to_string(seconds) + " s", false);
+  }
+  Logger &addInfo(const std::string &s) { return add(LogLevel::INFO, "", s, false); }
+  Logger &addWarning(const std::string &s) { return add(LogLevel::WARNING, "WARNING: ", s, false); }
+  Logger &addError(const std::string &s, bool = true) { return add(LogLevel::ERROR, "ERROR: ", s, true); }
+  void print(std::ostream &out = std::cout) {
+    (toError_ ? std::cerr : out) << pending_;
+    pending_.clear();
+    toError_ = false;
+  }
+};
 
 // vcRNG.hpp: viennacore::RNG is std::mt19937_64.  Here a thin wrapper with the same
 // UniformRandomBitGenerator interface that also counts the outputs drawn: a host-side Source
@@ -454,49 +510,73 @@ template <typename NumericType, int D>
   Normalize(randomDirection);
   return randomDirection;
 }
+// ReflectionConedCosine (rayReflection.hpp:52-120) assembled from two pieces of this library's own: the frame
+// around the mirror direction and the accept-reject draw of the lobe's polar angle.  The arithmetic (types,
+// operation order, engine outputs consumed) is the reference's — tests/aux/facade_units.cpp compares 10^5
+// samples bit for bit with the oracle's restatement — the code is not.
+namespace detail {
+// two unit vectors completing `axis` (unit length) to a right-handed frame; the closed form has its pole at -z
+template <typename NumericType> struct LobeFrame {
+  Vec3D<NumericType> u, v;
+  explicit LobeFrame(const Vec3D<NumericType> &axis) {
+    const NumericType one(1);
+    if (axis[2] < NumericType(-0.999999)) {
+      u = Vec3D<NumericType>{NumericType(0), -one, NumericType(0)};
+      v = Vec3D<NumericType>{-one, NumericType(0), NumericType(0)};
+      return;
+    }
+    const NumericType k = one / (one + axis[2]);
+    const NumericType mixed = -axis[0] * axis[1] * k;
+    u = Vec3D<NumericType>{one - axis[0] * axis[0] * k, mixed, -axis[0]};
+    v = Vec3D<NumericType>{mixed, one - axis[1] * axis[1] * k, -axis[1]};
+  }
+  // the direction with polar angle (sin, cos) = (sp, cp) and azimuth (sin, cos) = (sa, ca) about `axis`
+  Vec3D<NumericType> at(const Vec3D<NumericType> &axis, NumericType sp, NumericType cp, NumericType sa, NumericType ca) const {
+    Vec3D<NumericType> r;
+    for (int k = 0; k < 3; ++k)
+      r[k] = sp * (ca * u[k] + sa * v[k]) + cp * axis[k];
+    return r;
+  }
+};
+// polar angle of the cosine lobe squeezed into [0, cone]: proposals theta = cone * sqrt(1 - sqrt(U1)) are accepted
+// when U2 * theta * sqrt(U1) <= cos(pi/2 * theta / cone) * sin(theta); two engine outputs per proposal
+inline double lobePolarAngle(RNG &rng, double cone) {
+  std::uniform_real_distribution<double> unit(0.0, 1.0);
+  while (true) {
+    const double rootU = std::sqrt(unit(rng));
+    const double frac = std::sqrt(std::max(1.0 - rootU, 0.0));
+    const double theta = cone * frac;
+    const double bound = std::cos(M_PI_2 * frac) * std::sin(theta);
+    if (unit(rng) * theta * rootU <= bound)
+      return theta;
+  }
+}
+} // namespace detail
+
 template <typename NumericType, int D>
 [[nodiscard]] Vec3D<NumericType> ReflectionConedCosine(const Vec3D<NumericType> &rayDir, const Vec3D<NumericType> &geomNormal,
                                                        RNG &rng, const NumericType maxConeAngle) {
-  std::uniform_real_distribution<double> rand01(0.0, 1.0);
-  if (maxConeAngle <= NumericType(0))
+  // the two ends of the family: a mirror, and the plain cosine lobe about the normal
+  if (!(maxConeAngle > NumericType(0)))
     return ReflectionSpecular<NumericType>(rayDir, geomNormal);
   if (maxConeAngle >= M_PI_2)
     return ReflectionDiffuse<NumericType, D>(geomNormal, rng);
-  const auto v = Inv(rayDir);
-  Vec3D<NumericType> w = NumericType(NumericType(2) * DotProduct(geomNormal, v)) * geomNormal - v;
-  Normalize(w);
-  Vec3D<NumericType> t, b;
-  if (w[2] < NumericType(-0.999999)) {
-    t = {NumericType(0), NumericType(-1), NumericType(0)};
-    b = {NumericType(-1), NumericType(0), NumericType(0)};
-  } else {
-    const NumericType a = NumericType(1) / (NumericType(1) + w[2]);
-    const NumericType bx = -w[0] * w[1] * a, by = NumericType(1) - w[1] * w[1] * a;
-    t = {NumericType(1) - w[0] * w[0] * a, bx, -w[0]};
-    b = {bx, by, -w[1]};
-  }
-  double theta;
-  for (;;) {
-    const double u = std::sqrt(rand01(rng));
-    const double s = std::sqrt(std::max(1.0 - u, 0.0));
-    theta = maxConeAngle * s;
-    const double rhs = std::cos(M_PI_2 * s) * std::sin(theta);
-    if (rand01(rng) * theta * u <= rhs)
-      break;
-  }
-  const NumericType sinT = std::sin(theta);
-  const NumericType cosT = std::cos(theta);
-  const double phi = 2.0 * M_PI * rand01(rng);
-  NumericType sinP = std::sin(phi), cosP = std::cos(phi);
-  Vec3D<NumericType> dir{sinT * (cosP * t[0] + sinP * b[0]) + cosT * w[0], sinT * (cosP * t[1] + sinP * b[1]) + cosT * w[1],
-                         sinT * (cosP * t[2] + sinP * b[2]) + cosT * w[2]};
-  const NumericType dp = DotProduct(dir, geomNormal);
-  if (dp <= NumericType(0))
-    dir = dir - NumericType(NumericType(2) * dp) * geomNormal;
+  Vec3D<NumericType> mirror = ReflectionSpecular<NumericType>(rayDir, geomNormal);
+  Normalize(mirror);
+  const detail::LobeFrame<NumericType> frame(mirror);
+  const double theta = detail::lobePolarAngle(rng, maxConeAngle);
+  const NumericType sinTheta = std::sin(theta), cosTheta = std::cos(theta);
+  std::uniform_real_distribution<double> unit(0.0, 1.0);
+  const double azimuth = 2.0 * M_PI * unit(rng);
+  const NumericType sinAz = std::sin(azimuth), cosAz = std::cos(azimuth);
+  Vec3D<NumericType> out = frame.at(mirror, sinTheta, cosTheta, sinAz, cosAz);
+  // a sample below the surface is mirrored back above it
+  if (const NumericType below = DotProduct(out, geomNormal); below <= NumericType(0))
+    out = out - NumericType(NumericType(2) * below) * geomNormal;
   if constexpr (D == 2)
-    dir[2] = NumericType(0);
-  Normalize(dir);
-  return dir;
+    out[2] = NumericType(0);
+  Normalize(out);
+  return out;
 }
 
 // raySource.hpp:10-19
@@ -509,49 +589,49 @@ public:
   virtual NumericType getInitialRayWeight(const size_t) const { return 1.; }
 };
 
-// raySourceGrid.hpp:10-74.  Runs natively in the generator kernel (vr_set_source_grid).
+// SourceGrid (raySourceGrid.hpp:9-74): rays start at explicit grid points (origin = grid[idx mod n]) with a
+// power-cosine direction about the tracing axis.  The tracer recognises the type and runs it in the generator
+// kernel (vr_set_source_grid); this host version exists for user code that calls it directly and follows the
+// reference's arithmetic (float cosf / sinf / sqrtf, two engine outputs per ray).
 template <typename NumericType, int D> class SourceGrid : public Source<NumericType> {
   using boundingBoxType = std::array<Vec3D<NumericType>, 2>;
 
 public:
   SourceGrid(const boundingBoxType &boundingBox, std::vector<Vec3D<NumericType>> &sourceGrid, NumericType cosinePower,
              const std::array<int, 5> &traceSettings)
-      : bdBox_(boundingBox), sourceGrid_(sourceGrid), numPoints_(sourceGrid.size()), rayDir_(traceSettings[0]),
-        firstDir_(traceSettings[1]), secondDir_(traceSettings[2]), minMax_(traceSettings[3]), posNeg_(traceSettings[4]),
-        ee_(static_cast<NumericType>(2) / (cosinePower + 1)) {}
+      : box_(boundingBox), points_(sourceGrid), axis_{traceSettings[0], traceSettings[1], traceSettings[2]},
+        sign_(static_cast<NumericType>(traceSettings[4])), exponent_(NumericType(2) / (cosinePower + NumericType(1))) {}
 
   std::array<Vec3D<NumericType>, 2> getOriginAndDirection(const size_t idx, RNG &rngState) const override {
-    auto origin = sourceGrid_[idx % numPoints_];
-    Vec3D<NumericType> direction{0., 0., 0.};
-    std::uniform_real_distribution<NumericType> uniDist;
-    auto r1 = uniDist(rngState);
-    auto r2 = uniDist(rngState);
-    NumericType tt = pow(r2, ee_);
-    direction[rayDir_] = posNeg_ * sqrtf(tt);
-    direction[firstDir_] = cosf(M_PI * 2.f * r1) * sqrtf(1.f - tt);
-    if constexpr (D == 2)
-      direction[secondDir_] = 0;
-    else
-      direction[secondDir_] = sinf(M_PI * 2.f * r1) * sqrtf(1.f - tt);
-    Normalize(direction);
-    return {origin, direction};
+    std::uniform_real_distribution<NumericType> unit;
+    const NumericType azimuthDraw = unit(rngState);
+    const NumericType polarDraw = unit(rngState);
+    const NumericType cosSq = pow(polarDraw, exponent_); // cos^2 of the polar angle
+    const float along = sqrtf(cosSq), across = sqrtf(1.f - cosSq);
+    Vec3D<NumericType> d{NumericType(0), NumericType(0), NumericType(0)};
+    d[axis_[0]] = sign_ * along;
+    d[axis_[1]] = cosf(M_PI * 2.f * azimuthDraw) * across;
+    if constexpr (D == 3)
+      d[axis_[2]] = sinf(M_PI * 2.f * azimuthDraw) * across;
+    Normalize(d);
+    return {points_[idx % points_.size()], d};
   }
-  [[nodiscard]] size_t getNumPoints() const override { return numPoints_; }
+  [[nodiscard]] size_t getNumPoints() const override { return points_.size(); }
+  // the face of the bounding box the rays start from
   NumericType getSourceArea() const override {
-    if constexpr (D == 2)
-      return bdBox_[1][firstDir_] - bdBox_[0][firstDir_];
-    else
-      return (bdBox_[1][firstDir_] - bdBox_[0][firstDir_]) * (bdBox_[1][secondDir_] - bdBox_[0][secondDir_]);
+    NumericType area = box_[1][axis_[1]] - box_[0][axis_[1]];
+    if constexpr (D == 3)
+      area *= box_[1][axis_[2]] - box_[0][axis_[2]];
+    return area;
   }
-  [[nodiscard]] const std::vector<Vec3D<NumericType>> &getGrid() const { return sourceGrid_; }
+  [[nodiscard]] const std::vector<Vec3D<NumericType>> &getGrid() const { return points_; }
 
 private:
-  const boundingBoxType bdBox_;
-  const std::vector<Vec3D<NumericType>> &sourceGrid_;
-  const size_t numPoints_;
-  const int rayDir_, firstDir_, secondDir_, minMax_;
-  const NumericType posNeg_;
-  const NumericType ee_;
+  const boundingBoxType box_;
+  const std::vector<Vec3D<NumericType>> &points_;
+  const std::array<int, 3> axis_; // tracing axis, first and second transverse axis
+  const NumericType sign_;        // rays travel towards -/+ the tracing axis
+  const NumericType exponent_;
 };
 
 #define VIENNARAY_PARTICLE_STOP                                                                                         \
@@ -886,6 +966,7 @@ public:
     if (auto *g = dynamic_cast<SourceGrid<NumericType, D> *>(pSource_.get())) {
       auto pts = flatten3(g->getGrid());
       check(vr_set_source_grid(ctx_, pts.data(), (uint32_t)g->getGrid().size()));
+      check(vr_set_source_area(ctx_, (float)g->getSourceArea()));
       sourceOnDevice_ = true;
     }
   }
@@ -894,6 +975,8 @@ public:
     sourceOnDevice_ = false;
     if (ctx_)
       check(vr_set_source_grid(ctx_, nullptr, 0)); // also drops host rays
+    if (ctx_)
+      check(vr_set_source_area(ctx_, 0.f));
   }
   void enableProgressBar() {}
   void disableProgressBar() {}
@@ -948,10 +1031,13 @@ protected:
       std::cerr << "viennaray_amd: host-callback Source: number of rays must be in [1, 2^32).\n";
       return false;
     }
-    std::vector<float> org(numRays * 3), dir(numRays * 3);
+    std::vector<float> org(numRays * 3), dir(numRays * 3), weights(numRays);
     std::vector<uint32_t> draws(numRays);
+    bool unitWeights = true;
     auto particle = pParticle_->clone();
     for (size_t idx = 0; idx < numRays; ++idx) {
+      weights[idx] = (float)pSource_->getInitialRayWeight(idx); // rayTraceKernel.hpp:124
+      unitWeights = unitWeights && weights[idx] == 1.f;
       RNG rng(tea<3>((unsigned)idx, seed));
       particle->initNew(rng);
       auto pd = particle->initNewWithDirection(rng);
@@ -964,7 +1050,11 @@ protected:
       }
       draws[idx] = (uint32_t)rng.draws;
     }
-    const int rc = vr_set_host_rays(ctx_, org.data(), dir.data(), draws.data(), numRays);
+    int rc = vr_set_host_rays(ctx_, org.data(), dir.data(), draws.data(), numRays);
+    if (rc == VR_OK && !unitWeights)
+      rc = vr_set_host_ray_weights(ctx_, weights.data(), numRays);
+    if (rc == VR_OK)
+      rc = vr_set_source_area(ctx_, (float)pSource_->getSourceArea()); // rayTraceDisk.hpp:127: the source's own area
     if (rc != VR_OK) {
       RTInfo_.error = true;
       std::cerr << vr_last_error(ctx_) << "\n";

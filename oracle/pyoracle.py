@@ -53,6 +53,9 @@ def lib():
         L.orc_set_wdist.argtypes = [vp, C.c_int]
         L.orc_set_source_grid.argtypes = [vp, fp, C.c_uint]
         L.orc_set_host_rays.argtypes = [vp, fp, fp, C.c_uint]
+        L.orc_set_host_ray_weights.argtypes = [vp, fp, C.c_uint]
+        L.orc_set_host_ray_draws.argtypes = [vp, C.POINTER(C.c_uint), C.c_uint]
+        L.orc_set_source_area.argtypes = [vp, C.c_float]
         L.orc_create_source_grid.argtypes = [vp, C.c_uint64, C.c_float, fp, C.c_uint]
         L.orc_create_source_grid.restype = C.c_uint
         L.orc_num_data.argtypes = [vp]
@@ -215,9 +218,18 @@ class Oracle:
             a = _f32(pts).reshape(-1, 3)
             self.L.orc_set_source_grid(self.h, _fp(a), a.shape[0])
 
-    def set_host_rays(self, org, dirn):
+    def set_host_rays(self, org, dirn, weights=None, source_area=None):
         o, d = _f32(org).reshape(-1, 3), _f32(dirn).reshape(-1, 3)
         self.L.orc_set_host_rays(self.h, _fp(o), _fp(d), o.shape[0])
+        if weights is not None:
+            w = _f32(weights)
+            assert w.size == o.shape[0]
+            self.L.orc_set_host_ray_weights(self.h, _fp(w), w.size)
+        self.L.orc_set_source_area(self.h, float(source_area) if source_area is not None else 0.0)
+
+    def set_host_ray_draws(self, draws):
+        k = np.ascontiguousarray(draws, dtype=np.uint32)
+        self.L.orc_set_host_ray_draws(self.h, k.ctypes.data_as(C.POINTER(C.c_uint)), k.size)
 
     def create_source_grid(self, num_points, grid_delta):
         out = np.empty((int(num_points) * 2 + 64, 3), dtype=np.float32)

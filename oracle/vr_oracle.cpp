@@ -739,6 +739,9 @@ struct Context {
   std::vector<Vec3> sourceGrid;
   // sourceKind 2: explicit rays (what a user Source callback returned for idx), no draws consumed
   std::vector<Vec3> hostOrg, hostDir;
+  std::vector<unsigned> hostDraws; // engine outputs the user source consumed for ray idx (empty: none)
+  std::vector<float> hostWeights; // Source::getInitialRayWeight(idx) of a user source (empty: 1, raySource.hpp:18)
+  float sourceAreaOverride = 0.f; // Source::getSourceArea() of a user source (<= 0: SourceRandom's)
   // KernelConfig (rayUtil.hpp:83-94)
   uint64_t numRaysPerPoint = 1000, numRaysFixed = 0;
   unsigned maxReflections = std::numeric_limits<unsigned>::max();
@@ -1277,7 +1280,8 @@ static void traceRay(Context &c, long long idx, unsigned seed, float *flux,
   auto particleSeed = tea<3>((unsigned)idx, seed);
   RNG rngState(particleSeed);
 
-  const float initialRayWeight = 1.f; // Source::getInitialRayWeight
+  // rayTraceKernel.hpp:124: pSource_->getInitialRayWeight(idx) (raySource.hpp:18: 1 unless a user source overrides it)
+  const float initialRayWeight = (c.sourceKind == 2 && !c.hostWeights.empty()) ? c.hostWeights[(size_t)idx] : 1.f;
   float rayWeight = initialRayWeight;
   Vec3 rayDirection;
   unsigned numReflections = 0, boundaryHits = 0;
@@ -1288,6 +1292,9 @@ static void traceRay(Context &c, long long idx, unsigned seed, float *flux,
     if (c.sourceKind == 2) {
       o = c.hostOrg[(size_t)idx];
       d = c.hostDir[(size_t)idx];
+      // (the callback drew from this ray's engine: raySource.hpp:14-15 hands it `RNG &rngState`)
+      for (unsigned k = 0; !c.hostDraws.empty() && k < c.hostDraws[(size_t)idx]; ++k)
+        (void)rngState();
     } else if (c.sourceKind == 1)
       sourceGridSample(c, idx, rngState, o, d);
     else
@@ -1595,7 +1602,8 @@ static void normalizeFlux(const Context &c, float *flux, int norm) {
       for (unsigned i = 0; i < N; ++i)
         flux[i] *= (totalDiskArea / c.diskAreas[i]) / maxv;
     } else {
-      const float normFactor = c.sourceArea / c.numRaysLast;
+      // rayTraceDisk.hpp:127: pSource_->getSourceArea()
+      const float normFactor = (c.sourceAreaOverride > 0.f ? c.sourceAreaOverride : c.sourceArea) / c.numRaysLast;
       for (unsigned i = 0; i < N; ++i)
         flux[i] *= normFactor / c.diskAreas[i];
     }
@@ -1605,7 +1613,7 @@ static void normalizeFlux(const Context &c, float *flux, int norm) {
       for (unsigned i = 0; i < N; ++i)
         flux[i] /= maxv * c.triAreas[i];
     } else {
-      const float normFactor = c.sourceArea / c.numRaysLast;
+      const float normFactor = (c.sourceAreaOverride > 0.f ? c.sourceAreaOverride : c.sourceArea) / c.numRaysLast;
       for (unsigned i = 0; i < N; ++i)
         flux[i] *= normFactor / c.triAreas[i];
     }
@@ -1714,7 +1722,13 @@ void orc_set_host_rays(Context *c, const float *org, const float *dir, unsigned 
     c->hostDir.push_back(orc::Vec3{dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]});
   }
   c->sourceKind = n ? 2 : 0;
+  c->hostWeights.clear();
+  c->hostDraws.clear();
 }
+void orc_set_host_ray_draws(Context *c, const unsigned *k, unsigned n) { c->hostDraws.assign(k, k + n); }
+// Source::getInitialRayWeight(idx) of the host rays (n == 0: all 1) and Source::getSourceArea() (<= 0: SourceRandom's)
+void orc_set_host_ray_weights(Context *c, const float *w, unsigned n) { c->hostWeights.assign(w, w + n); }
+void orc_set_source_area(Context *c, float area) { c->sourceAreaOverride = area > 0.f ? area : 0.f; }
 // createSourceGrid (rayUtil.hpp:564-611) on the prepared bounding box; returns the point count
 unsigned orc_create_source_grid(Context *c, uint64_t numPoints, float gridDelta, float *out, unsigned cap) {
   orc::prepare(*c);
@@ -1915,6 +1929,35 @@ int orc_boundary_process_hit(Context *c, float *org, float *dir, float tfar,
 void orc_wall_normal(Context *c, unsigned primID, float *Ng) {
   for (int k = 0; k < 3; ++k)
     Ng[k] = c->wall[primID].Ng[k];
+}
+// ReflectionConedCosine (rayReflection.hpp:52-120) for hand-made inputs: sample i uses std::mt19937_64(seed0 + i)
+// and cone angle cones[i % ncones]; tests compare the drop-in facade's host function with this bit for bit
+void orc_reflection_coned_cosine(int D, unsigned seed0, int n, const float *rayDirs, const float *normals,
+                                 const float *cones, int ncones, float *out) {
+  for (int i = 0; i < n; ++i) {
+    orc::StdRNG rng(seed0 + (unsigned)i);
+    const orc::Vec3 rd{rayDirs[3 * i], rayDirs[3 * i + 1], rayDirs[3 * i + 2]};
+    const orc::Vec3 nn{normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
+    const orc::Vec3 r = orc::ReflectionConedCosine(D, rd, nn, rng, cones[i % ncones]);
+    for (int k = 0; k < 3; ++k)
+      out[3 * i + k] = r[k];
+  }
+}
+// SourceGrid::getOriginAndDirection's direction (raySourceGrid.hpp:25-52) for engine std::mt19937_64(seed0 + i)
+void orc_source_grid_direction(int D, int rayDir, int firstDir, int secondDir, int posNeg, float cosinePower,
+                               unsigned seed0, int n, float *out) {
+  orc::Context c;
+  c.D = D;
+  c.ts = {rayDir, firstDir, secondDir, 0, posNeg};
+  c.sourcePower = cosinePower;
+  c.sourceGrid.push_back(orc::Vec3{0.f, 0.f, 0.f});
+  for (int i = 0; i < n; ++i) {
+    orc::StdRNG rng(seed0 + (unsigned)i);
+    orc::Vec3 o, d;
+    orc::sourceGridSample(c, i, rng, o, d);
+    for (int k = 0; k < 3; ++k)
+      out[3 * i + k] = d[k];
+  }
 }
 int orc_max_threads() {
 #ifdef _OPENMP

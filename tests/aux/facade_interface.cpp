@@ -1,7 +1,9 @@
-// The reference's API walk (tests/traceInterface/traceInterface.cpp:8-70) on the drop-in façade,
-// extended over the extension points of SURVEY 8f N2: a user Source (host callback), SourceGrid, a
+// Run-time walk over the drop-in façade's public API (the method list of SURVEY.md 8(b)), then the extension points of
+// a user Source (host callback), SourceGrid, a
 // plug-in particle with two data labels, a coned-cosine particle, and a host-only user particle
-// (which must be refused, not silently replaced).  Needs a GPU to run; it must always COMPILE.
+// (which must be refused, not silently replaced).  Needs a GPU to run; it must always COMPILE.  (That the reference's
+// own tests/traceInterface and examples compile against the façade unchanged is checked on their sources in place:
+// tests/test_facade_units.py::test_reference_sources_compile_against_the_facade.)
 #include <rayParticle.hpp>
 #include <raySourceGrid.hpp>
 #include <rayTraceDisk.hpp>
@@ -19,17 +21,13 @@ using namespace viennaray;
     }                                                                                                                  \
   } while (0)
 
-// tests/traceInterface/traceInterface.cpp:7-22, verbatim in shape
-template <typename NumericType, int D> class MySource : public Source<NumericType> {
-public:
-  MySource() {}
-  std::array<Vec3D<NumericType>, 2> getOriginAndDirection(const size_t idx, RNG &rngState) const override {
-    Vec3D<NumericType> origin{0., 0., 0.};
-    Vec3D<NumericType> direction{0., 0., 1.};
-    return {origin, direction};
+// the smallest possible user Source: one fixed ray, no points (set and dropped again before the first apply)
+template <typename T> struct PinnedRaySource final : Source<T> {
+  std::array<Vec3D<T>, 2> getOriginAndDirection(const size_t, RNG &) const override {
+    return {Vec3D<T>{T(0), T(0), T(0)}, Vec3D<T>{T(0), T(0), T(1)}};
   }
   size_t getNumPoints() const override { return 0; }
-  NumericType getSourceArea() const override { return 1; }
+  T getSourceArea() const override { return T(1); }
 };
 
 // a source that shoots straight down from above a given point and draws one number per ray
@@ -60,45 +58,78 @@ public:
   std::vector<std::string> getLocalDataLabels() const override { return {"mine"}; }
 };
 
+// Every public method of Trace / TraceDisk that SURVEY.md 8(b) lists, once, on a flat 21 x 21 cloud (the plane of the
+// reference's tests/traceInterface: 441 points x 10 rays per point = 4410 rays, its one known answer).
+static void api_walk(TraceDisk<float, 3> &tracer, const std::vector<Vec3D<float>> &cloud,
+                     const std::vector<Vec3D<float>> &cloudNormals, float delta) {
+  using T = float;
+  // configuration first, geometry last: the setters are order independent
+  tracer.setUseRandomSeeds(false);
+  tracer.setNumberOfRaysPerPoint(10);
+  tracer.setSourceDirection(TraceDirection::POS_Z);
+  BoundaryCondition walls[3] = {BoundaryCondition::REFLECTIVE_BOUNDARY, BoundaryCondition::REFLECTIVE_BOUNDARY,
+                                BoundaryCondition::REFLECTIVE_BOUNDARY};
+  tracer.setBoundaryConditions(walls);
+  tracer.setMaxReflections(1000);
+  tracer.setMaxBoundaryHits(500);
+  std::unique_ptr<DiffuseParticle<T, 3>> absorber = std::make_unique<DiffuseParticle<T, 3>>(T(1), "hitFlux");
+  tracer.setParticleType(absorber);
+  tracer.setGeometry(cloud, cloudNormals, delta);
+  tracer.setMaterialIds(std::vector<T>(cloud.size(), T(0)));
+  // a user source that is dropped again leaves the built-in random source in charge
+  tracer.setSource(std::make_shared<PinnedRaySource<T>>());
+  tracer.resetSource();
+  tracer.apply();
+
+  const TraceInfo first = tracer.getRayTraceInfo();
+  VC_TEST_ASSERT(!first.error);
+  VC_TEST_ASSERT(first.numRays == 4410);                            // tests/traceInterface/traceInterface.cpp:67
+  VC_TEST_ASSERT(first.geometryHits + first.nonGeometryHits == 4410); // absorbing: one outcome per ray
+  VC_TEST_ASSERT(first.totalRaysTraced == first.geometryHits + first.nonGeometryHits + first.boundaryHits);
+  TracingData<T> &local = tracer.getLocalData();
+  VC_TEST_ASSERT(local.getVectorDataIndex("hitFlux") == 0 && local.getVectorData("hitFlux").size() == cloud.size());
+  std::vector<T> raw = local.getVectorData(0);
+  double credited = 0;
+  for (T v : raw)
+    credited += v;
+  VC_TEST_ASSERT(credited >= (double)first.geometryHits); // the closest disk and every overlapping neighbour
+  std::vector<T> shaped = raw;
+  tracer.normalizeFlux(shaped);                      // SOURCE
+  tracer.smoothFlux(shaped, 2);                      // two-neighbourhood
+  VC_TEST_ASSERT(shaped.size() == cloud.size());
+  std::vector<T> byMax = raw;
+  tracer.normalizeFlux(byMax, NormalizationType::MAX);
+  T top = 0;
+  for (size_t k = 0; k < byMax.size(); ++k)
+    top = std::max(top, byMax[k]);
+  VC_TEST_ASSERT(top >= T(1));                       // the largest raw value maps to >= 1 (area correction at the rim)
+  // the same seed again: the same flux, bit for bit (tests/rngSeed/rngSeed.cpp:48-51) — apply() advanced runNumber
+  tracer.setRngSeed(0);
+  tracer.apply();
+  const std::vector<T> second = tracer.getLocalData().getVectorData(0);
+  tracer.setRngSeed(1); // seed + runNumber: (1, run 2) != (0, run 2)
+  tracer.apply();
+  const std::vector<T> third = tracer.getLocalData().getVectorData(0);
+  VC_TEST_ASSERT(second != third);
+  // borrowed global data comes back as it went in; the data log is reachable
+  TracingData<T> global;
+  global.setNumberOfVectorData(1);
+  global.setVectorData(0, cloud.size(), T(0.25), "coverage");
+  tracer.setGlobalData(global);
+  VC_TEST_ASSERT(tracer.getGlobalData() == &global && tracer.getGlobalData()->getVectorData("coverage")[7] == T(0.25));
+  (void)tracer.getDataLog();
+  std::printf("traceInterface: numRays %zu geometryHits %zu\n", first.numRays, first.geometryHits);
+}
+
 int main() {
   constexpr int D = 3;
   using NumericType = float;
-  NumericType extent = 5;
-  NumericType gridDelta = 0.5;
-  std::vector<VectorType<NumericType, D>> points;
-  std::vector<VectorType<NumericType, D>> normals;
+  const NumericType extent = 5, gridDelta = 0.5;
+  std::vector<VectorType<NumericType, D>> points, normals;
   rayInternal::createPlaneGrid(gridDelta, extent, {0, 1, 2}, points, normals);
-  std::vector<NumericType> matIds(points.size(), 0);
-
-  BoundaryCondition boundaryConds[D];
-  boundaryConds[0] = BoundaryCondition::REFLECTIVE_BOUNDARY;
-  boundaryConds[1] = BoundaryCondition::REFLECTIVE_BOUNDARY;
-  boundaryConds[2] = BoundaryCondition::REFLECTIVE_BOUNDARY;
-  auto particle = std::make_unique<DiffuseParticle<NumericType, D>>(NumericType(1), "hitFlux");
-
+  VC_TEST_ASSERT(points.size() == 441);
   TraceDisk<NumericType, D> rayTracer;
-  rayTracer.setParticleType(particle);
-  rayTracer.setGeometry(points, normals, gridDelta);
-  rayTracer.setBoundaryConditions(boundaryConds);
-  rayTracer.setSourceDirection(TraceDirection::POS_Z);
-  rayTracer.setNumberOfRaysPerPoint(10);
-  rayTracer.setUseRandomSeeds(false);
-  rayTracer.setMaterialIds(matIds);
-
-  auto mySource = std::make_shared<MySource<NumericType, D>>();
-  rayTracer.setSource(mySource);
-  rayTracer.resetSource();
-  rayTracer.apply();
-
-  auto flux = rayTracer.getLocalData().getVectorData(0);
-  VC_TEST_ASSERT(flux.size() == points.size());
-  rayTracer.normalizeFlux(flux);
-  rayTracer.smoothFlux(flux, 2);
-  VC_TEST_ASSERT(flux.size() == points.size());
-  auto info = rayTracer.getRayTraceInfo();
-  VC_TEST_ASSERT(info.numRays == 4410); // traceInterface.cpp:67
-  VC_TEST_ASSERT(!info.error);
-  std::printf("traceInterface: numRays %zu geometryHits %zu\n", info.numRays, info.geometryHits);
+  api_walk(rayTracer, points, normals, gridDelta);
 
   { // host-callback source: every ray comes straight down at y = 0.3 -> only the disks under that line
     rayTracer.setRngSeed(7);

@@ -29,7 +29,7 @@ def _expected(total, n):
     return int(acc.sum()), int(acc.dot(np.arange(n, dtype=np.int64) % 1000003) % (1 << 61))
 
 
-@pytest.mark.parametrize("gpus", [1, 2, 3])
+@pytest.mark.parametrize("gpus", [1, 2, 3, 8])
 def test_gpus_flag_starts_that_many_ranks_weak(gpus):
     out = _run(["--gpus", str(gpus), "--steps", "2", "--warmup", "0", "--stub-shard", "--grid", "50", "--rays", "10007"])
     assert out["n_gpus"] == gpus and out["scaling"] == "weak"
@@ -45,6 +45,15 @@ def test_total_rays_is_strong_scaling():
     assert one["scaling"] == two["scaling"] == "strong"
     assert one["total_rays"] == two["total_rays"] == 30001
     assert (one["acc_sum"], one["acc_checksum"]) == (two["acc_sum"], two["acc_checksum"]) == _expected(30001, 2500)
+
+
+def test_eight_ranks_strong_scaling_like_c3():
+    """The driver's eventual C3 command shape, `bench.py --gpus 8 --total-rays R`: eight ranks, contiguous
+    shares of ONE global index range (a prime-ish R: unequal shares), every ray traced exactly once."""
+    out = _run(["--gpus", "8", "--steps", "1", "--warmup", "0", "--stub-shard", "--grid", "50", "--total-rays", "1000003"])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["total_rays"] == 1000003
+    assert (out["acc_sum"], out["acc_checksum"]) == _expected(1000003, 2500)
+    assert out["counters"]["totalRaysTraced"] == 1000003
 
 
 def test_world_size_mismatch_is_an_error():

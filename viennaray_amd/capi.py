@@ -26,7 +26,7 @@ class TraceInfoPOD(C.Structure):
                 ("time", C.c_double), ("timeBuild", C.c_double), ("timeTrace", C.c_double),
                 ("timeTraceKernel", C.c_double),
                 ("warning", C.c_int32), ("error", C.c_int32), ("rngFullStates", C.c_uint64),
-                ("timeGenKernel", C.c_double)]
+                ("timeGenKernel", C.c_double), ("bvhRefits", C.c_uint32), ("bvhBuilds", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -60,6 +60,9 @@ SIGNATURES = {
     "vr_set_use_wdist": (C.c_int, [_vp, C.c_int]),
     "vr_set_source_grid": (C.c_int, [_vp, _fp, C.c_uint32]),
     "vr_set_host_rays": (C.c_int, [_vp, _fp, _fp, _u32p, C.c_uint64]),
+    "vr_set_host_ray_weights": (C.c_int, [_vp, _fp, C.c_uint64]),
+    "vr_set_source_area": (C.c_int, [_vp, C.c_float]),
+    "vr_reserve_rays": (C.c_int, [_vp, C.c_uint64]),
     "vr_set_number_of_rays_per_point": (C.c_int, [_vp, C.c_uint64]),
     "vr_set_number_of_rays_fixed": (C.c_int, [_vp, C.c_uint64]),
     "vr_set_max_reflections": (C.c_int, [_vp, C.c_uint32]),

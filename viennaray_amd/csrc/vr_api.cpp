@@ -36,6 +36,20 @@ template <class T> struct DevBuf {
       cap = std::max<size_t>(n, 1);
     return e;
   }
+  // buffers whose size follows the ray count of an apply(): grown by half again, so a simulation whose
+  // ray count creeps up from step to step re-allocates O(log) times, not every step (hipMalloc of a
+  // multi-GB ray stream costs tens of ms)
+  hipError_t ensure_grow(size_t n) {
+    if (n <= cap && p)
+      return hipSuccess;
+    const size_t want = std::max(n, cap + cap / 2);
+    hipError_t e = ensure(want);
+    if (e != hipSuccess && want > n) { // (no room for the head-room: the exact size)
+      (void)hipGetLastError();
+      e = ensure(n);
+    }
+    return e;
+  }
   void release() {
     if (p)
       (void)hipFree(p);
@@ -80,8 +94,11 @@ struct vr_context {
   std::vector<float> gridPoints;  // SourceGrid origins (raySourceGrid.hpp)
   std::vector<float> hostOrg, hostDir;
   std::vector<uint32_t> hostDraws;
+  std::vector<float> hostWeights;  // Source::getInitialRayWeight(idx) of the host rays (empty: 1)
+  float sourceAreaOverride = 0.f;  // Source::getSourceArea() of a user source (<= 0: SourceRandom's, the bbox face)
+  uint64_t reserveRays = 0;        // vr_reserve_rays: the ray-stream buffers hold at least this many rays
   bool sourceDirty = false;
-  DevBuf<float> dGrid, dHostOrg, dHostDir;
+  DevBuf<float> dGrid, dHostOrg, dHostDir, dHostWeights;
   DevBuf<uint32_t> dHostDraws;
   float sticking = 1.f, sourcePower = 1.f;
   std::vector<int32_t> matStickIds;
@@ -92,6 +109,8 @@ struct vr_context {
   bool useRandomSeed = true;
   uint32_t runNumber = 1;
   uint64_t rayFirst = 0, rayCount = 0;
+  bool haveSharedSeed = false; // vr_apply_sharded + useRandomSeed: rank 0's draw, handed round by the all-reduce
+  uint32_t sharedSeed = 0;
 
   // derived at prepare()
   float bbLo[3], bbHi[3];
@@ -109,6 +128,7 @@ struct vr_context {
   // device buffers
   DevBuf<float> dNodes, dPrims, dPrimSticking;
   DevBuf<float> dAreas, dFluxTmp;     // exposed area per primitive (caller's order); normalisation scratch
+  DevBuf<uint32_t> dNormMax;          // flux_max_kernel's reduction word
   bool areasValid = false;
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
   uint32_t nbTotal = 0;               // entries of the resident neighbourhood CSR
@@ -137,6 +157,7 @@ struct vr_context {
   bool haveSetup = false;
   int builtOrderAxis = -1;       // child order of the resident BVH (source side first)
   int bvhRefits = 0;             // 1 if the last build had to be re-fitted with agent-scope fences
+  uint32_t bvhBuilds = 0;        // scene builds of this context
   float builtOrderSign = 0.f;
   DevBuf<unsigned long long> dKeysA, dKeysB;
   bool hostOrderValid = false;   // c->bvh.order mirrors dOrder
@@ -367,6 +388,7 @@ int vr_set_source_grid(vr_context *c, const float *points3, uint32_t n) {
   c->hostOrg.clear();
   c->hostDir.clear();
   c->hostDraws.clear();
+  c->hostWeights.clear();
   c->sourceDirty = true;
   c->prepared = false;
   return VR_OK;
@@ -382,8 +404,38 @@ int vr_set_host_rays(vr_context *c, const float *org3, const float *dir3, const 
     c->hostDraws.assign(draws, draws + (size_t)n);
   else
     c->hostDraws.clear();
+  c->hostWeights.clear();
   c->gridPoints.clear();
   c->sourceDirty = true;
+  c->prepared = false;
+  return VR_OK;
+}
+// Source::getInitialRayWeight(idx) (raySource.hpp:18, rayTraceKernel.hpp:124) of the rays handed over with
+// vr_set_host_rays: the weight a ray starts with and the scale of the roulette's thresholds.  n == 0: all 1.
+int vr_set_host_ray_weights(vr_context *c, const float *weights, uint64_t n) {
+  if (!c || (n && !weights))
+    return fail(c, VR_E_INVALID, "vr_set_host_ray_weights: bad argument");
+  if (n && n != c->hostOrg.size() / 3)
+    return fail(c, VR_E_INVALID, "vr_set_host_ray_weights: one weight per host ray (call vr_set_host_rays first)");
+  c->hostWeights.assign(weights, weights + (size_t)n);
+  c->sourceDirty = true;
+  c->prepared = false;
+  return VR_OK;
+}
+// Source::getSourceArea() (raySource.hpp:17) of a user source, used by normalizeFlux(SOURCE)
+// (rayTraceDisk.hpp:127); area <= 0 restores SourceRandom's (the source face of the bounding box)
+int vr_set_source_area(vr_context *c, float area) {
+  if (!c)
+    return VR_E_INVALID;
+  c->sourceAreaOverride = area > 0.f ? area : 0.f;
+  return VR_OK;
+}
+// apply() is called once per time step with a ray count that follows the surface: reserve the ray-stream
+// buffers for the largest count expected (they also grow by half again on their own and are kept)
+int vr_reserve_rays(vr_context *c, uint64_t n) {
+  if (!c)
+    return VR_E_INVALID;
+  c->reserveRays = n;
   c->prepared = false;
   return VR_OK;
 }
@@ -733,6 +785,15 @@ static int effective_direction(const vr_context *c) {
   return c->geo.D == 2 ? VR_POS_Y : VR_POS_Z; // rayTrace.hpp:166-167
 }
 
+// rayTraceKernel.hpp:57-61: numRaysFixed, or source.getNumPoints() * numRaysPerPoint
+// (SourceRandom: the geometry's points; SourceGrid: the grid's; host rays: exactly those given)
+static uint64_t rays_of_apply(const vr_context *c) {
+  if (!c->hostOrg.empty())
+    return c->hostOrg.size() / 3;
+  const uint64_t srcPoints = !c->gridPoints.empty() ? c->gridPoints.size() / 3 : c->geo.numPrims;
+  return c->numRaysFixed == 0 ? srcPoints * c->numRaysPerPoint : c->numRaysFixed;
+}
+
 int vr_apply_prepare(vr_context *c) {
   if (!c)
     return VR_E_INVALID;
@@ -800,6 +861,7 @@ int vr_apply_prepare(vr_context *c) {
     if (r != VR_OK)
       return r;
     c->geometryDirty = false;
+    ++c->bvhBuilds;
     c->builtOrderAxis = c->ts[0];
     c->builtOrderSign = c->ts[3] ? 1.f : -1.f;
   }
@@ -860,12 +922,7 @@ int vr_apply_prepare(vr_context *c) {
   const float *dStick = c->havePrimSticking ? c->dPrimSticking.p : nullptr;
   c->configDirty = false;
 
-  // rayTraceKernel.hpp:57-61: numRaysFixed, or source.getNumPoints() * numRaysPerPoint
-  // (SourceRandom: the geometry's points; SourceGrid: the grid's; host rays: exactly those given)
-  const uint64_t srcPoints = !c->gridPoints.empty() ? c->gridPoints.size() / 3 : N;
-  uint64_t numRays = c->numRaysFixed == 0 ? srcPoints * c->numRaysPerPoint : c->numRaysFixed;
-  if (!c->hostOrg.empty())
-    numRays = c->hostOrg.size() / 3;
+  const uint64_t numRays = rays_of_apply(c);
   c->numRaysLast = numRays;
   uint64_t first = 0, last = numRays;
   if (c->rayCount) {
@@ -875,7 +932,9 @@ int vr_apply_prepare(vr_context *c) {
   c->rayFirstLaunch = first;
   c->rayEndLaunch = last;
   uint32_t seed = c->runNumber + c->rngSeed; // rayTraceKernel.hpp:100
-  if (c->useRandomSeed) {
+  if (c->haveSharedSeed) { // (vr_apply_sharded with random seeds: the one seed every rank agreed on)
+    seed = c->sharedSeed;
+  } else if (c->useRandomSeed) {
     std::random_device rd;
     seed = (uint32_t)rd();
   }
@@ -888,6 +947,8 @@ int vr_apply_prepare(vr_context *c) {
   const bool extended = c->particleKind >= VR_PARTICLE_CONED_COSINE || c->useWdist || c->meanFreePath > 0.f;
   if (extended)
     c->absorb = false;
+  if (!c->hostOrg.empty() && !c->hostWeights.empty())
+    c->absorb = false; // (the absorbing kernels credit unit weights)
   // (the rare, register-hungry options — coned-cosine model, WDIST crediting, mean free path — have an instantiation
   //  of their own: multi-label and per-material particles should not pay for them)
   const bool extFull = c->particleKind == (int)P_CONED_COSINE || c->useWdist || c->meanFreePath > 0.f;
@@ -944,6 +1005,10 @@ int vr_apply_prepare(vr_context *c) {
         VR_HIP(c, c->dHostDraws.ensure(c->hostDraws.size()));
         VR_HIP(c, hipMemcpy(c->dHostDraws.p, c->hostDraws.data(), c->hostDraws.size() * 4, hipMemcpyHostToDevice));
       }
+      if (!c->hostWeights.empty()) {
+        VR_HIP(c, c->dHostWeights.ensure(c->hostWeights.size()));
+        VR_HIP(c, hipMemcpy(c->dHostWeights.p, c->hostWeights.data(), c->hostWeights.size() * 4, hipMemcpyHostToDevice));
+      }
     }
     c->sourceDirty = false;
   }
@@ -978,11 +1043,20 @@ int vr_apply_prepare(vr_context *c) {
     const size_t slots = (size_t)nb * binCap + cap; // bins + overflow region
     c->slotStride = slots;
     const size_t recFloats = c->absorb ? 8 : 12; // 32 B, or 32 B + the 16-B RNG cursors
-    VR_HIP(c, c->dSlotRec.ensure(slots * recFloats));
-    VR_HIP(c, c->dBinCount.ensure((size_t)nb + 1));
+    size_t slotsWant = slots, binsWant = (size_t)nb + 1;
+    if (c->reserveRays > span) { // vr_reserve_rays: room for the largest apply() announced
+      TraceParams q = p;
+      uint32_t nbR = 0;
+      const uint32_t capR = (uint32_t)std::min<uint64_t>(c->reserveRays, 1ull << 27);
+      size_bins(D, capR, perBin, q, nbR);
+      slotsWant = std::max(slotsWant, (size_t)nbR * binCap + capR);
+      binsWant = std::max(binsWant, (size_t)nbR + 1);
+    }
+    VR_HIP(c, c->dSlotRec.ensure_grow(slotsWant * recFloats));
+    VR_HIP(c, c->dBinCount.ensure_grow(binsWant));
     if (c->overlap) {
-      VR_HIP(c, c->dSlotRec2.ensure(slots * recFloats));
-      VR_HIP(c, c->dBinCount2.ensure((size_t)nb + 1));
+      VR_HIP(c, c->dSlotRec2.ensure_grow(slots * recFloats));
+      VR_HIP(c, c->dBinCount2.ensure_grow((size_t)nb + 1));
     }
   }
 
@@ -1079,6 +1153,7 @@ int vr_apply_prepare(vr_context *c) {
   p.hostOrg = c->hostOrg.empty() ? nullptr : c->dHostOrg.p;
   p.hostDir = c->hostOrg.empty() ? nullptr : c->dHostDir.p;
   p.hostDraws = c->hostDraws.empty() ? nullptr : c->dHostDraws.p;
+  p.hostWeights = (c->hostOrg.empty() || c->hostWeights.empty()) ? nullptr : c->dHostWeights.p;
   p.accMask = c->accReplicas - 1u;
   p.counters = c->dCounters.p;
   p.workCounter = c->dCounters.p + 8;
@@ -1308,7 +1383,7 @@ int vr_apply_finish(vr_context *c) {
     if (cnt[60]) {
       c->launched = false;
       c->prepared = false;
-      return fail(c, VR_E_STATE, "BVH traversal stack overflow (degenerate tree): result discarded");
+      return fail(c, VR_E_STATE, "BVH traversal stack overflow (degenerate tree), or a rank of a sharded apply failed: result discarded");
     }
   }
 #ifdef VR_SELFCHECK
@@ -1357,6 +1432,8 @@ int vr_apply_finish(vr_context *c) {
   i.timeGenKernel = gms * 1e-3;
   i.timeBuild = c->buildSeconds;
   i.time = i.timeBuild + i.timeTrace;
+  i.bvhRefits = (uint32_t)c->bvhRefits;
+  i.bvhBuilds = c->bvhBuilds;
   ++c->runNumber; // rayTraceDisk.hpp:54
   c->launched = false;
   c->prepared = false;
@@ -1383,37 +1460,79 @@ int vr_apply(vr_context *c) {
 int vr_apply_sharded(vr_context *c, int rank, int world, vr_allreduce_fn reduce, void *user) {
   if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !reduce))
     return fail(c, VR_E_INVALID, "vr_apply_sharded: bad argument");
-  c->rayFirst = 0;
-  c->rayCount = 0;
-  int r = vr_apply_prepare(c); // (also yields the total number of rays of this apply)
-  if (r != VR_OK)
-    return r;
-  const uint64_t total = c->numRaysLast;
+  VR_HIP(c, hipSetDevice(c->device));
+  const uint64_t total = rays_of_apply(c);
   const uint64_t first = total * (uint64_t)rank / (uint64_t)world;
   const uint64_t last = total * (uint64_t)(rank + 1) / (uint64_t)world;
   const uint32_t N = c->geo.numPrims;
+  VR_HIP(c, c->dCounters.ensure(80));
+  c->haveSharedSeed = false;
+  if (world > 1 && c->useRandomSeed) {
+    // setUseRandomSeeds(true): every rank would draw its own seed and the shards would belong to different
+    // streams.  Rank 0 draws, the others contribute 0, and the all-reduce hands the seed round.
+    unsigned long long word = 0;
+    if (rank == 0) {
+      std::random_device rd;
+      word = (uint32_t)rd();
+    }
+    VR_HIP(c, hipMemcpyAsync(c->dCounters.p + 63, &word, 8, hipMemcpyHostToDevice, c->stream));
+    if (reduce(user, c->dCounters.p + 63, 1, (void *)c->stream) != 0)
+      return fail(c, VR_E_HIP, "vr_apply_sharded: the all-reduce callback failed (seed)");
+    VR_HIP(c, hipMemcpyAsync(&word, c->dCounters.p + 63, 8, hipMemcpyDeviceToHost, c->stream));
+    VR_HIP(c, hipStreamSynchronize(c->stream));
+    c->sharedSeed = (uint32_t)word;
+    c->haveSharedSeed = true;
+  }
+  int r = VR_OK;
   if (last > first) {
     c->rayFirst = first;
     c->rayCount = last - first;
     r = vr_apply_prepare(c);
     if (r == VR_OK)
       r = vr_apply_launch(c);
-    c->rayFirst = 0;
-    c->rayCount = 0;
-    if (r != VR_OK)
-      return r;
   } else {
-    VR_HIP(c, hipMemsetAsync(c->fluxOut(), 0, (size_t)N * c->numData * 8, c->stream));
-    VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 80 * 8, c->stream));
-    VR_HIP(c, hipEventRecord(c->ev0, c->stream));
-    VR_HIP(c, hipEventRecord(c->ev1, c->stream));
-    c->numBatches = 0;
-    c->launched = true;
+    // an empty share: nothing to trace, but the scene is prepared like everywhere else (numRays, areas,
+    // accumulator planes: the collective below must see the same buffer sizes on every rank)
+    c->rayFirst = total; // (an empty range behind the last ray)
+    c->rayCount = 1;
+    r = vr_apply_prepare(c);
+    if (r == VR_OK) {
+      VR_HIP(c, hipMemsetAsync(c->fluxOut(), 0, (size_t)N * c->numData * 8, c->stream));
+      VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 80 * 8, c->stream));
+      VR_HIP(c, hipEventRecord(c->ev0, c->stream));
+      VR_HIP(c, hipEventRecord(c->ev1, c->stream));
+      c->numBatches = 0;
+      c->launched = true;
+    }
   }
+  c->rayFirst = 0;
+  c->rayCount = 0;
+  c->haveSharedSeed = false;
   if (world > 1) {
+    // A rank that failed above still enters the collectives when it can (zeros and a raised failure word) —
+    // the others would hang in them otherwise.  The TraceInfo counters [0..7] AND the failure word [60] (the
+    // walk's stack overflow, or this) travel together: every rank fails together, none returns VR_OK
+    // holding sums that include a discarded share.
+    const std::string firstErr = c->err;
+    const bool haveBuf = c->boundFlux ? c->boundFluxN == N * c->numData : c->dFluxOrig.cap >= (size_t)N * c->numData;
+    if (r != VR_OK) {
+      if (!haveBuf)
+        return r; // (failed before the accumulators existed: a configuration error, the same on every rank)
+      const unsigned long long one = 1;
+      (void)hipMemsetAsync(c->fluxOut(), 0, (size_t)N * c->numData * 8, c->stream);
+      (void)hipMemsetAsync(c->dCounters.p, 0, 80 * 8, c->stream);
+      (void)hipMemcpyAsync(c->dCounters.p + 60, &one, 8, hipMemcpyHostToDevice, c->stream);
+    }
     if (reduce(user, c->fluxOut(), (size_t)N * c->numData, (void *)c->stream) != 0 ||
-        reduce(user, c->dCounters.p, 8, (void *)c->stream) != 0)
+        reduce(user, c->dCounters.p, 64, (void *)c->stream) != 0)
       return fail(c, VR_E_HIP, "vr_apply_sharded: the all-reduce callback failed");
+    if (r != VR_OK) {
+      (void)hipStreamSynchronize(c->stream);
+      c->err = firstErr;
+      return r;
+    }
+  } else if (r != VR_OK) {
+    return r;
   }
   return vr_apply_finish(c);
 }
@@ -1532,13 +1651,14 @@ static int normalize_on_device(vr_context *c, uint32_t n, int normType) {
   if (normType == VR_NORM_SOURCE) {
     if (c->numRaysLast == 0)
       return fail(c, VR_E_STATE, "No source was specified in rayTrace for the normalization.");
-    normFactor = c->sourceArea / c->numRaysLast;
+    normFactor = (c->sourceAreaOverride > 0.f ? c->sourceAreaOverride : c->sourceArea) / c->numRaysLast;
   } else if (normType != VR_NORM_MAX) {
     return VR_OK; // `default: break;` in the reference
   }
   const double totalDiskArea = c->geo.diskRadius * c->geo.diskRadius * M_PI;
+  VR_HIP(c, c->dNormMax.ensure(1)); // (a word of its own: the builder's scratch does not exist under VR_HOST_BUILD)
   VR_HIP(c, launch_normalize_flux(c->dFluxTmp.p, c->dAreas.p, n, disk ? 0 : 1, normType, normFactor, totalDiskArea,
-                                  c->dBounds.p + 7, c->stream));
+                                  c->dNormMax.p, c->stream));
   return VR_OK;
 }
 
@@ -1659,7 +1779,9 @@ int vr_get_bounding_box(vr_context *c, float *out6) {
   }
   return VR_OK;
 }
-float vr_get_source_area(vr_context *c) { return c ? c->sourceArea : 0.f; }
+float vr_get_source_area(vr_context *c) {
+  return c ? (c->sourceAreaOverride > 0.f ? c->sourceAreaOverride : c->sourceArea) : 0.f;
+}
 float vr_get_disk_radius(const vr_context *c) { return c ? c->geo.diskRadius : 0.f; }
 int vr_get_neighbor_counts(vr_context *c, uint32_t *out, uint32_t n) {
   if (!c || !out || n != c->geo.numPrims)

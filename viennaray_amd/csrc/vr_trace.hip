@@ -515,10 +515,14 @@ trace_kernel(const TraceParams p) {
   // the 80 VGPRs (left to the register allocator they went to scratch, and a scratch reload waits on the
   // vector-memory counter: for every load and atomic the wave has in flight).
   constexpr bool COLD_IN_LDS = !ABSORB && !SMALL;
-  __shared__ unsigned coldS[COLD_IN_LDS ? 2 * VR_BLOCK : 1];
+  __shared__ unsigned coldS[COLD_IN_LDS ? 3 * VR_BLOCK : 1];
   unsigned numReflectionsR = 0, boundaryHitsR = 0;
   unsigned &numReflections = COLD_IN_LDS ? coldS[tid] : numReflectionsR;
   unsigned &boundaryHits = COLD_IN_LDS ? coldS[VR_BLOCK + tid] : boundaryHitsR;
+  // Source::getInitialRayWeight(idx) (rayTraceKernel.hpp:124): 1 for every built-in source; a host-callback source may
+  // hand over its own (p.hostWeights, wave-uniform test).  Read again only by the roulette's thresholds.
+  unsigned initWeightR = 0x3F800000u;
+  unsigned &initWeightBits = COLD_IN_LDS ? coldS[2 * VR_BLOCK + tid] : initWeightR;
   bool hitFromBack = false;
   bool start = false; // this lane begins a new trace segment in this round
   unsigned node = VR_END; // cursor of the lane's BVH walk (VR_END: none under way)
@@ -622,6 +626,10 @@ trace_kernel(const TraceParams p) {
         rayDirection = mk(a.w, b.x, b.y);
         dir = project_dir<D>(rayDirection); // what Embree sees (rayUtil.hpp:204-227)
         rayWeight = 1.f;                    // Source::getInitialRayWeight
+        if (!ABSORB && p.hostWeights) {     // (a host-callback source with weights of its own never runs an absorbing kernel)
+          rayWeight = p.hostWeights[p.batchFirst + __float_as_uint(b.z)];
+          initWeightBits = __float_as_uint(rayWeight);
+        }
         numReflections = 0;
         boundaryHits = 0;
         hitFromBack = false;
@@ -932,8 +940,9 @@ trace_kernel(const TraceParams p) {
                   active = false;
                 } else {
                   // rejectionControl, :435-460
-                  const float lowerThreshold = (float)(0.1 * 1.0);
-                  const float renewWeight = (float)(0.3 * 1.0);
+                  const float initWeight = p.hostWeights ? __uint_as_float(initWeightBits) : 1.f;
+                  const float lowerThreshold = (float)(0.1 * (double)initWeight);
+                  const float renewWeight = (float)(0.3 * (double)initWeight);
                   bool reflect = true;
                   if (!(rayWeight >= lowerThreshold)) {
                     DIAG(10);

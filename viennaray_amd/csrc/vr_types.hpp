@@ -90,6 +90,7 @@ struct TraceParams {
   float eeGrid;
   const float *hostOrg, *hostDir;
   const uint32_t *hostDraws;
+  const float *hostWeights;      // Source::getInitialRayWeight(idx) of a host-callback source (nullptr: 1, raySource.hpp:18)
   unsigned long long *counters;  // [8]
   unsigned long long *workCounter;
   unsigned long long *rngScratch; // [waves][312][64]

@@ -273,7 +273,9 @@ class Trace:
             return
         raise VrError("setSource: host-callback sources go through setHostRays(origins, directions, draws)")
 
-    def setHostRays(self, origins, directions, draws=None):
+    def setHostRays(self, origins, directions, draws=None, weights=None, sourceArea=None):
+        """Rays of a host-callback Source (raySource.hpp:10-19): origin, direction, engine outputs consumed and —
+        if the source overrides them — getInitialRayWeight(idx) per ray and getSourceArea()."""
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
         assert o.shape == d.shape
@@ -284,10 +286,20 @@ class Trace:
         self._check(self._L.vr_set_host_rays(self._h, _fptr(o), _fptr(d),
                                              k.ctypes.data_as(C.POINTER(C.c_uint32)) if k is not None else None,
                                              o.shape[0]))
+        if weights is not None:
+            w = np.ascontiguousarray(weights, dtype=np.float32)
+            assert w.size == o.shape[0]
+            self._check(self._L.vr_set_host_ray_weights(self._h, _fptr(w), w.size))
+        self._check(self._L.vr_set_source_area(self._h, float(sourceArea) if sourceArea is not None else 0.0))
+
+    def reserveRays(self, n):
+        """Size the HBM ray stream for applies of up to n rays (apply() per time step with a growing count)."""
+        self._check(self._L.vr_reserve_rays(self._h, int(n)))
 
     def resetSource(self):
         """rayTrace.hpp:58-61"""
         self._check(self._L.vr_set_source_grid(self._h, None, 0))
+        self._check(self._L.vr_set_source_area(self._h, 0.0))
 
     def setBoundaryConditions(self, bcs):
         a = (C.c_int32 * len(bcs))(*[int(b) for b in bcs])
