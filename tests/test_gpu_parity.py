@@ -813,6 +813,46 @@ def test_device_bvh_is_consistent_after_every_rebuild():
     assert m.getRayTraceInfo().bvhRefits == 0
 
 
+def test_apply_wall_time_is_device_time_when_the_ray_count_grows():
+    """apply() once per time step with a ray count that follows the surface: the ray-stream buffers grow
+    geometrically and are kept, so the SECOND apply after a 50-fold increase costs its device time plus < 2 ms of
+    host work (round 2: 66 ms of re-allocation on trenchGrid3D.dat), and a reservation makes the first one cheap too."""
+    import time
+    gd, p, n = trench3d()
+
+    def tracer():
+        t = vr.TraceDisk(3)
+        t.setGeometry(p, n, gd)
+        t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+        t.setParticleType(vr.DiffuseParticle(0.1, "flux"))
+        t.setRngSeed(12345)
+        return t
+
+    def timed(t, rays):
+        t.setNumberOfRaysFixed(rays)
+        t.setRunNumber(1)
+        t0 = time.perf_counter()
+        t.apply()
+        wall = time.perf_counter() - t0
+        return (wall - t.getRayTraceInfo().timeTrace) * 1e3, info_dict(t)
+
+    t = tracer()
+    timed(t, 1_000_000)
+    timed(t, 50_000_000)                  # grows the stream (allocation: not asserted)
+    host2, i2 = timed(t, 50_000_000)
+    assert host2 < 2.0, host2
+    host3, _ = timed(t, 55_000_000)       # +10 %: inside the head-room of the last growth
+    assert host3 < 2.0, host3
+    host4, i4 = timed(t, 1_000_000)       # shrinking keeps the buffers
+    assert host4 < 2.0, host4
+    r = tracer()
+    r.reserveRays(50_000_000)
+    timed(r, 1_000_000)                   # allocates the reservation
+    host5, i5 = timed(r, 50_000_000)      # first apply at the big count: nothing left to allocate
+    assert host5 < 2.0, host5
+    assert i5 == i2                       # (and none of this changes a result)
+
+
 # ---------------------------------------------------------------------------
 # randomised differential test: random scenes / settings, HIP path vs oracle
 # ---------------------------------------------------------------------------
@@ -1531,7 +1571,7 @@ def test_apply_sharded_ranks_sum_to_the_whole():
             t.setRunNumber(1)
             calls.clear()
             t.applySharded(rank, world, cb, None)
-            assert calls == [t._n, 8]
+            assert calls == [t._n, 64]   # the flux, then counters [0..7] together with the failure word [60]
             parts.append(t.getFluxF64())
             infos.append(info_dict(t))
         assert (sum(parts) == whole).all()

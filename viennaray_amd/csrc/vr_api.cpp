@@ -133,6 +133,7 @@ struct vr_context {
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
   uint32_t nbTotal = 0;               // entries of the resident neighbourhood CSR
   DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
+  DevBuf<unsigned long long> dWorkQ;  // span cursors of the trace kernel's per-XCD queues (two sets: overlap mode)
   size_t scratchWaves = 0;
   // flux accumulators are replicated accReplicas times (power of two, stride accStride
   // elements); a block credits replica blockIdx & (accReplicas-1): small scenes would
@@ -1156,7 +1157,9 @@ int vr_apply_prepare(vr_context *c) {
   p.hostWeights = (c->hostOrg.empty() || c->hostWeights.empty()) ? nullptr : c->dHostWeights.p;
   p.accMask = c->accReplicas - 1u;
   p.counters = c->dCounters.p;
-  p.workCounter = c->dCounters.p + 8;
+  VR_HIP(c, c->dWorkQ.ensure(2 * VR_QUEUES * VR_QUEUE_STRIDE));
+  p.workCounter = c->dWorkQ.p;
+  p.numQueues = VR_QUEUES;
   p.rngScratch = c->dScratch.p;
   p.slotRec = c->dSlotRec.p;
   p.binCount = c->dBinCount.p;
@@ -1272,7 +1275,15 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
     p.slotRec = c->dSlotRec2.p;
     p.binCount = c->dBinCount2.p;
   }
-  p.workCounter = c->dCounters.p + 8 + slot;
+  p.workCounter = c->dWorkQ.p + (size_t)slot * VR_QUEUES * VR_QUEUE_STRIDE;
+  // One queue per XCD pays where neighbouring rounds share primitive records that do not fit an XCD's 4 MiB L2 and the
+  // work per bin is even: flat scenes of more than ~10^5 primitives (measured, VR_QUEUES=1 / 8 on one box: C2 sticking
+  // 0.1 15.62 -> 15.16 ms, C2 1.0 6.67 -> 6.62, plane 100^2 +-0).  A structured scene is L2 resident anyway and its
+  // bins differ in cost — an eighth of the trench is not an eighth of the work: trench3D +3 %, C5 +6 %: one queue.
+  const bool flat = c->traceMode == 1 || c->traceMode == 3;
+  p.numQueues = (flat && c->geo.numPrims > (1u << 17) && nbBatch >= 64u * VR_QUEUES * p.chunk) ? VR_QUEUES : 1u;
+  if (const char *e = std::getenv("VR_QUEUES"))
+    p.numQueues = std::atoi(e) >= (int)VR_QUEUES ? VR_QUEUES : 1u;
   hipStream_t sg = c->overlap ? c->stream2 : c->stream;
   while (c->evK.size() < 2 * (batchNo + 1)) {
     hipEvent_t e;
@@ -1303,7 +1314,7 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
     VR_HIP(c, hipEventRecord(c->evSort[batchNo], sg));
     VR_HIP(c, hipStreamWaitEvent(c->stream, c->evSort[batchNo], 0));
   }
-  VR_HIP(c, hipMemsetAsync(p.workCounter, 0, 8, c->stream));
+  VR_HIP(c, hipMemsetAsync(p.workCounter, 0, VR_QUEUES * VR_QUEUE_STRIDE * 8, c->stream));
   VR_HIP(c, hipEventRecord(c->evK[2 * batchNo], c->stream));
   // a small batch does not need the whole persistent grid: one wave per 64 rays is plenty
   const unsigned gridBatch =

@@ -545,6 +545,8 @@ trace_kernel(const TraceParams p) {
   const unsigned totalBins = p.numBins + (ovCount + p.binCap - 1) / p.binCap;
   unsigned curBin = 0, spanStart = 0, spanEnd = 0, curOff = 0, curCnt = 0, curBase = 0;
   unsigned spanCounts = 0; // lane i: ray count of bin spanStart + i
+  const unsigned myQueue = blockIdx.x & (p.numQueues - 1u); // (numQueues is 1 or 8)
+  unsigned qTried = 0;                      // queues this wave has found empty (wave-uniform)
   unsigned packetSkip = 0, packetFails = 0; // wave-uniform back-off of packet attempts
   unsigned pqSkip = 0, pqFails = 0;         // ... and of packet-query attempts
   bool exhausted = false;
@@ -580,16 +582,32 @@ trace_kernel(const TraceParams p) {
           if (curBin + 1 >= spanEnd || spanEnd == 0) {
             if (exhausted)
               break;
-            unsigned long long s = 0;
-            if (lane == 0)
-              s = atomicAdd(p.workCounter, (unsigned long long)p.chunk);
-            s = bcast64(s);
-            if (s >= totalBins) {
+            // One queue of bins PER XCD: queue q owns the q-th eighth of the (spatially ordered) bins, the waves of
+            // an XCD (blockIdx & 7 labels the blocks that share one) drain their own queue first and then help
+            // with the others.  The rounds that follow each other on an XCD are then neighbours in space: the
+            // primitive records one round pulled into the XCD's L2 serve the next (one global queue dealt
+            // neighbouring spans to all eight L2s: 37 line misses per C2 round beyond its ray records).
+            unsigned lo = 0, hi = 0;
+            for (; qTried < p.numQueues; ++qTried) {
+              const unsigned q = (myQueue + qTried) & (p.numQueues - 1u);
+              const unsigned qLo = (unsigned)((unsigned long long)totalBins * q / p.numQueues);
+              const unsigned qHi = (unsigned)((unsigned long long)totalBins * (q + 1u) / p.numQueues);
+              unsigned long long s = 0;
+              if (lane == 0)
+                s = atomicAdd(p.workCounter + (size_t)q * VR_QUEUE_STRIDE, (unsigned long long)p.chunk);
+              s = bcast64(s);
+              if (s < (unsigned long long)(qHi - qLo)) {
+                lo = qLo + (unsigned)s;
+                hi = (lo + p.chunk < qHi) ? lo + p.chunk : qHi;
+                break;
+              }
+            }
+            if (lo == hi) { // every queue is empty
               exhausted = true;
               break;
             }
-            curBin = spanStart = (unsigned)s;
-            spanEnd = (unsigned)((s + p.chunk < totalBins) ? s + p.chunk : totalBins);
+            curBin = spanStart = lo;
+            spanEnd = hi;
             // the span's bin counts in one coalesced load (lane i <- bin spanStart + i; chunk <= 64)
             const unsigned bi = spanStart + lane;
             spanCounts = (bi < spanEnd && bi < p.numBins) ? p.binCount[bi] : 0u;

@@ -36,6 +36,8 @@ struct Tri {       // boundary wall triangle, Embree's precomputed form
 constexpr unsigned VR_BIN_CAP = 128; // record slots per sort bin (4 KB of 32-byte records: the generator's scattered stores
                                     // and the bin cursors do better with bins a page apart than with 64 slots)
 constexpr int VR_BLOCK = 256;
+constexpr unsigned VR_QUEUES = 8;        // work queues of the trace kernel: one per XCD
+constexpr unsigned VR_QUEUE_STRIDE = 16; // u64 words between two queue cursors
 // stack of the ordered per-lane walk: the first entries of a lane live in LDS ([entry][lane], 12 in
 // the kernels that walk a lot, 4 in the absorbing flat-scene kernel), deeper ones in a per-wave global slab
 constexpr unsigned VR_STACK_GLOBAL = 48;
@@ -92,7 +94,8 @@ struct TraceParams {
   const uint32_t *hostDraws;
   const float *hostWeights;      // Source::getInitialRayWeight(idx) of a host-callback source (nullptr: 1, raySource.hpp:18)
   unsigned long long *counters;  // [8]
-  unsigned long long *workCounter;
+  unsigned long long *workCounter; // numQueues span cursors, VR_QUEUE_STRIDE words apart (a 128-byte line each)
+  uint32_t numQueues;              // 1, or 8: one queue of sort bins per XCD (vr_trace.hip, refill)
   unsigned long long *rngScratch; // [waves][312][64]
   // ray stream of the current batch: VR_BIN_CAP record slots per sort bin, then the
   // overflow region (rays whose bin was full), all in one array of 32-byte records
