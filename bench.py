@@ -200,34 +200,42 @@ COUNTER_NAMES = ("totalRaysTraced", "nonGeometryHits", "geometryHits", "boundary
                  "raysTerminated")
 
 
-def parity_sample(t, mk_oracle, total_rays, sample, threads):
+def parity_sample(t, mk_oracle, total_rays, sample, threads, first=0):
     """Flux L2-relative error (SOURCE-normalised) and TraceInfo differences, GPU vs the CPU oracle, on
-    the first `sample` rays of the `total_rays`-ray workload (same seed, same global ray indices)."""
+    `sample` rays from global index `first` of the `total_rays`-ray workload (same seed, same global ray indices)."""
     from oracle import pyoracle as po
     o = mk_oracle(po)
     o.set_num_rays_fixed(total_rays)
-    o.set_ray_range(0, sample)
+    o.set_ray_range(first, sample)
     o.set_rng_seed(12345)
     o.set_lazy_rng(True)  # same stream as std::mt19937_64 (tests/test_oracle_rng.py), cheaper to seed
     o.apply(threads)
     t.setNumberOfRaysFixed(total_rays)
     t.setRunNumber(1)
-    t.setRayRange(0, sample)
+    t.setRayRange(first, sample)
     t.apply()
     t.setRayRange(0, 0)
     f = t.normalizeFlux(t.getLocalData().getVectorData(0)).astype(np.float64)
     r = o.normalize_flux(o.flux()).astype(np.float64)
     gi, oi = t.getRayTraceInfo(), o.info()
     den = np.linalg.norm(r)
-    return dict(flux_l2_rel_err=float(np.linalg.norm(f - r) / den) if den > 0 else float(np.linalg.norm(f - r)),
+    return dict(parity_first_ray=first, flux_l2_rel_err=float(np.linalg.norm(f - r) / den) if den > 0 else float(np.linalg.norm(f - r)),
                 counter_diff={k: int(getattr(gi, k)) - oi[k] for k in COUNTER_NAMES}, parity_sample_rays=sample)
 
 
-def secondary_case(name, rays, sample, threads, sticking=None, reps=2):
+def secondary_case(name, rays, sample, threads, sticking=None, reps=2, ray_range=None, total_rays=None, sha=None,
+                   counters_key=None):
     """One non-headline workload: Mrays/s from the device pipeline time of a warmed apply()
-    (geometry resident), trace-kernel ms, and a parity sample against the oracle."""
+    (geometry resident), trace-kernel ms, a parity sample against the oracle and — when the committed PMC
+    profile holds this workload for this build — its roofline block.
+    ray_range = (first, count): trace only that slice of a `total_rays`-ray stream (C3: one rank's shard)."""
     t, mk_oracle, nprims, desc, D = workload(name, 0, sticking)
-    t.setNumberOfRaysFixed(rays)
+    total = total_rays or rays
+    t.setNumberOfRaysFixed(total)
+    if ray_range:
+        t.setRayRange(*ray_range)
+    t.setRunNumber(1)
+    t.apply()          # warm-up: scene build, buffers, code objects (not timed; wall below is a warmed apply)
     best = None
     for _ in range(reps):
         t.setRunNumber(1)
@@ -237,13 +245,22 @@ def secondary_case(name, rays, sample, threads, sticking=None, reps=2):
         info = t.getRayTraceInfo()
         if best is None or info.timeTrace < best["t"]:
             best = dict(t=info.timeTrace, k=info.timeTraceKernel, g=info.timeGenKernel, wall=wall,
-                        seg=int(info.totalRaysTraced))
-    out = dict(name=name, workload=f"{desc}, {rays} rays, seed 12345", rays=rays, segments=best["seg"],
+                        seg=int(info.totalRaysTraced), refits=int(info.bvhRefits))
+    out = dict(name=name, workload=f"{desc}, {rays} rays" + (f" = indices [{ray_range[0]}, {ray_range[0] + ray_range[1]}) of a "
+                                                              f"{total}-ray stream" if ray_range else "") + ", seed 12345",
+               rays=rays, segments=best["seg"],
                Mrays_per_s=round(rays / best["t"] / 1e6, 1), device_pipeline_ms=round(best["t"] * 1e3, 4),
                trace_kernel_ms=round(best["k"] * 1e3, 4), gen_kernel_ms=round(best["g"] * 1e3, 4),
-               apply_wall_ms=round(best["wall"] * 1e3, 3))
+               apply_wall_ms=round(best["wall"] * 1e3, 3), kernel_mode=t.traceMode(), bvh_refits=best["refits"])
+    if sha and counters_key:
+        r = roofline(sha, counters_key, best["k"] * 1e3, best["g"] * 1e3, best["seg"], rays)
+        if r.get("frac") is not None:
+            out["roofline"] = {k: r[k] for k in ("kernel", "kernel_ms", "profiled_kernel_ms", "bound", "achieved", "peak", "unit",
+                                                 "frac", "traffic", "l2_hit_rate", "useful_lane_frac", "lanes_per_valu_instr",
+                                                 "wave_instr_per_segment", "wait_frac") if k in r}
     if sample:
-        out.update(parity_sample(t, mk_oracle, rays, min(sample, rays), threads))
+        first = ray_range[0] if ray_range else 0
+        out.update(parity_sample(t, mk_oracle, total, min(sample, rays), threads, first))
     return out
 
 
@@ -367,9 +384,16 @@ def main():
         gavg = float(np.mean(gen_ms))
         abytes, b_hit, b_path = algorithmic_bytes(N, float(np.mean(geo)), float(np.mean(segs)))
         sha = lib_sha256()
-        roof = roofline(sha, n, rays_rank, args.sticking, tavg, gavg, kernel_name)
-        roof["algorithmic_GBs"] = round(abytes / (tavg * 1e-3) / 1e9, 2)
-        roof["algorithmic_bytes_per_hit_segment"] = round(b_hit, 1)
+        roof = roofline(sha, f"C2_s{args.sticking}" if n == 1000 else f"P{n}_s{args.sticking}", tavg, gavg,
+                        float(np.mean(segs)), rays_rank)
+        roof["kernel"] = roof.get("kernel") or kernel_name
+        # SURVEY 8(d)'s one-ray-at-a-time byte model, for the record: it prices every ray's own root-to-leaf path and
+        # neighbour records, while a wavefront of 64 sorted rays shares each fetch — it exceeds the HBM peak and is
+        # therefore NOT used as a fraction (round-2 verdict); `frac` above is counter bytes / time / 8 TB/s
+        roof["algorithmic_model"] = {"bytes_per_hit_segment": round(b_hit, 1), "bytes_per_launch": int(abytes),
+                                     "GBs": round(abytes / (tavg * 1e-3) / 1e9, 1),
+                                     "compulsory_bytes_per_launch": int(rays_rank * 32 + N * 40),
+                                     "note": "compulsory = every ray record read once (32 B) + every disk record and accumulator once"}
         out = {
             "metric": "Mrays/sec + flux L2-rel-err vs CPU oracle, 1M-disk 3D @1e8 rays",
             "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -389,6 +413,7 @@ def main():
             "segments_per_step": int(np.mean(segs)), "Msegments_per_s": round(np.mean(segs) / (kavg * 1e-3) / 1e6, 2),
             "trace_launches_per_step": int(math.ceil(rays_rank / float(1 << 27))),  # one per batch of <= 2^27 rays
             "prepare_s": round(build_s, 4), "lib_sha256": sha[:16],
+            "bvh_refits": int(info.bvhRefits) if info is not None else None,  # (0: the BVH fit's fast hand-over never needed its fenced retry)
             "roofline": roof,
         }
         if world == 1:
@@ -434,18 +459,29 @@ def main():
             if not args.no_secondary:
                 sec = []
                 tr = shard = None  # free the headline context's ray-stream buffers
-                for name, rays, sample, st in (("C2", args.rays, 2_000_000, 0.1),
-                                               ("C1_plane100", 1_000_000, 1_000_000, None),
-                                               ("C1_plane100", 100_000_000, 0, None),
-                                               ("C1_trench3d", 1_000_000, 1_000_000, None),
-                                               ("C1_trench3d", 57_838_000, 0, None),
-                                               ("C4", 100_000_000, 1_000_000, None),
-                                               ("C5p", 100_000_000, 1_000_000, None),
-                                               ("C5r", 100_000_000, 1_000_000, None)):
+                from viennaray_amd import distributed as vd2
+                c3 = vd2.ray_shard(1_000_000_000, 7, 8)   # C3: rank 7's shard of the 10^9-ray stream (one batch, like each of 8 GPUs)
+                cases = (dict(name="C2", rays=args.rays, sample=2_000_000, sticking=0.1, counters_key="C2_s0.1"),
+                         dict(name="C2", rays=c3[1], sample=2_000_000, sticking=1.0, ray_range=c3, total_rays=1_000_000_000,
+                              label="C3_shard"),
+                         dict(name="C1_plane100", rays=1_000_000, sample=1_000_000),
+                         dict(name="C1_plane100", rays=100_000_000, sample=0),
+                         dict(name="C1_trench3d", rays=1_000_000, sample=1_000_000),
+                         dict(name="C1_trench3d", rays=57_838_000, sample=0, counters_key="C1_trench3d"),
+                         dict(name="C4", rays=100_000_000, sample=1_000_000, counters_key="C4"),
+                         dict(name="C5p", rays=100_000_000, sample=1_000_000, counters_key="C5p"),
+                         dict(name="C5r", rays=100_000_000, sample=1_000_000))
+                for cs in cases:
+                    label = cs.pop("label", None)
+                    if args.no_parity:
+                        cs["sample"] = 0
                     try:
-                        sec.append(secondary_case(name, rays, 0 if args.no_parity else sample, threads, st))
+                        r = secondary_case(threads=threads, sha=sha, **cs)
+                        if label:
+                            r["name"] = label
+                        sec.append(r)
                     except Exception as e:  # a failing secondary must not hide the headline
-                        sec.append(dict(name=name, error=str(e)))
+                        sec.append(dict(name=label or cs["name"], error=str(e)))
                 out["secondary"] = sec
         print(json.dumps(out))
     if distributed:
@@ -454,72 +490,83 @@ def main():
 
 
 ISSUE_CLASSES = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS")
+_COUNTERS = None
 
 
-def roofline(sha, grid, rays, sticking, trace_ms, gen_ms, kernel_name):
-    """Instruction-issue roofline of the two hot kernels.
+def committed_counters(sha):
+    """profiles/counters_latest.json (tools/pmc_profile.py + tools/publish_counters.py), or None when it was taken
+    with another build: counts are combined with this run's kernel times only for the same library bytes or — a
+    rebuild need not be byte-identical — the same kernel sources."""
+    global _COUNTERS
+    if _COUNTERS is None:
+        try:
+            cj = json.load(open(os.path.join(ROOT, "profiles", "counters_latest.json")))
+        except Exception:  # noqa: BLE001
+            cj = {}
+        same = bool(cj) and (cj.get("lib_sha256") == sha or (cj.get("src_sha256") is not None and cj.get("src_sha256") == src_sha256()))
+        _COUNTERS = (cj, same)
+    return _COUNTERS
 
-    The tracer is not bandwidth bound (measured fabric traffic: hbm_frac below); what bounds it is the
-    rate at which a SIMD issues wave instructions.  tools/issue_ceiling.py measures that ceiling on the
-    device: ONE wave instruction of any class (VALU, SALU, ...) per ~2 cycles per SIMD — 0.44 (VALU only or
-    dependent VALU->SALU votes) to 0.49 (independent mix) per SIMD-cycle against the 0.5 the guide states
-    for VALU (MI355X_MICROARCH.md "Wave scheduling": a wave64 VALU instruction issues over 2 cycles).
-      achieved = wave instructions of all classes per launch / kernel time
-      peak     = 1024 SIMDs x 2.4 GHz / 2 cycles = 1228.8 G wave-instr/s
-    The instruction counts come from the committed rocprofv3 PMC profile (profiles/counters_latest.json,
-    SQ_INSTS_*) and are used ONLY when that profile was taken with the very library that is running
-    (sha256 of the .so) on the same workload; the kernel time is this run's (HIP events on the library's
-    stream).  valu_issue_frac / salu_issue_frac price the two big classes alone (SALU: one scalar unit
-    per CU, 1 / cycle)."""
-    peak = SIMDS * CLOCK_HZ / 2.0
-    roof = {"kernel": kernel_name, "bound": "issue", "achieved": None, "peak": round(peak / 1e9, 1),
-            "unit": "G wave-instr/s", "frac": None, "traffic": None}
-    path = os.path.join(ROOT, "profiles", "counters_latest.json")
-    try:
-        cj = json.load(open(path))
-    except Exception:
-        roof["note"] = "no committed PMC profile (profiles/counters_latest.json)"
-        return roof
-    # the profile belongs to this build: same library bytes, or — a rebuild need not be byte-identical —
-    # the same kernel sources
-    same_build = cj.get("lib_sha256") == sha or (cj.get("src_sha256") is not None and cj.get("src_sha256") == src_sha256())
-    same = (same_build and cj.get("grid") == grid and cj.get("rays") == rays and cj.get("sticking") == sticking)
+
+def kernel_block(k, ms, segments=None):
+    """One kernel's figures per launch: PMC counts of the committed profile over THIS run's kernel time (HIP
+    events on the library's stream).
+      frac = achieved / peak, achieved = fabric bytes of the L2s per launch ((2 FETCH_SIZE + WRITE_SIZE) KiB: the
+             guide's gfx950 correction; Infinity-Cache hits are included, so this is an UPPER bound of the HBM share)
+             / kernel time, peak = 8.0 TB/s.  The contract's roof — and not what limits these kernels:
+      useful_lane_frac, wave_instr_per_segment, lanes_per_valu_instr, wait_frac say what does (instruction issue on
+             partly filled wavefronts + exposed latency); they cannot be raised by executing more instructions."""
+    t = ms * 1e-3
+    out = {"kernel": k.get("name"), "kernel_ms": round(ms, 4), "profiled_kernel_ms": round(k["avg_ms"], 4) if k.get("avg_ms") else None,
+           "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None}
+    if k.get("hbm_bytes") is not None:
+        out["traffic"] = int(k["hbm_bytes"])
+        out["achieved"] = round(k["hbm_bytes"] / t / 1e9, 1)
+        out["frac"] = round(k["hbm_bytes"] / t / (HBM_PEAK_GBS * 1e9), 4)
+    for key, nd in (("l2_hit_rate", 4), ("dram_read_share", 4), ("useful_lane_frac", 4), ("lanes_per_valu_instr", 2),
+                    ("clock_ghz", 3), ("l1_miss_per_access", 4)):
+        if k.get(key) is not None:
+            out[key] = round(k[key], nd)
+    if k.get("SQ_WAIT_ANY_frac") is not None:
+        out["wait_frac"] = round(k["SQ_WAIT_ANY_frac"], 4)
+    if all(c in k for c in ISSUE_CLASSES):
+        total = sum(k[c] for c in ISSUE_CLASSES)
+        if segments:
+            out["wave_instr_per_segment"] = round(total / segments, 1)
+        # diagnostics only — NOT a roofline fraction: issued (not useful) instructions against the rate a SIMD
+        # reaches on the matching synthetic mix (tools/issue_ceiling.py; the guide's nominal figure is 0.5 / cycle)
+        out["issue_diag"] = {"wave_instructions_per_launch": {c[9:]: int(k[c]) for c in ISSUE_CLASSES},
+                             "per_simd_cycle": round(total / t / (SIMDS * CLOCK_HZ), 4)}
+    return out
+
+
+def roofline(sha, case, trace_ms, gen_ms, segments, rays):
+    """The `roofline` object of the bench line for workload `case` (a key of profiles/counters_latest.json)."""
+    cj, same = committed_counters(sha)
+    roof = {"kernel": None, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
     roof["counts_from"] = {"file": "profiles/counters_latest.json", "lib_sha256": str(cj.get("lib_sha256"))[:16],
-                           "src_sha256": str(cj.get("src_sha256"))[:16],
-                           "commit": cj.get("commit"), "matches_running_library_and_workload": bool(same)}
-    if not same:
-        roof["note"] = "committed PMC profile belongs to another build or workload: not combined with this run's timing"
+                           "src_sha256": str(cj.get("src_sha256"))[:16], "commit": cj.get("commit"),
+                           "matches_running_build": bool(same)}
+    c = (cj.get("cases") or {}).get(case)
+    if not same or not c or (c.get("rays") not in (None, rays)):
+        roof["note"] = "no committed PMC profile of this build and workload: counters are not combined with this run's timing"
         return roof
-
-    def block(k, ms):
-        t = ms * 1e-3
-        total = sum(k.get(c, 0.0) for c in ISSUE_CLASSES)
-        out = {"achieved": round(total / t / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
-               "frac": round(total / t / peak, 4), "kernel_ms": round(ms, 4), "profiled_kernel_ms": k.get("avg_ms"),
-               "wave_instructions_per_launch": {c[9:]: int(k.get(c, 0)) for c in ISSUE_CLASSES},
-               "valu_issue_frac": round(k.get("SQ_INSTS_VALU", 0) / t / VALU_PEAK, 4),
-               "salu_issue_frac": round((k.get("SQ_INSTS_SALU", 0) + k.get("SQ_INSTS_SMEM", 0)) / t / SALU_PEAK, 4),
-               "lanes_per_valu_instr": k.get("lanes_per_valu_instr"), "wait_frac": k.get("SQ_WAIT_ANY_frac"),
-               "clock_ghz_profiled": k.get("clock_ghz_profiled")}
-        if "hbm_bytes" in k:
-            out["traffic"] = k["hbm_bytes"]
-            out["hbm_frac"] = round(k["hbm_bytes"] / t / (HBM_PEAK_GBS * 1e9), 4)
-        return out
-
-    roof.update(block(cj["trace_kernel"], trace_ms))
-    if gen_ms > 0 and cj.get("gen_kernel"):
-        g = block(cj["gen_kernel"], gen_ms)
-        g["bound"] = "issue"
+    roof.update(kernel_block(c["trace_kernel"], trace_ms, segments))
+    roof["limiter"] = ("not HBM: the scene (BVH + records, MBs) is served from the L2s and the Infinity Cache, the ray records "
+                       "stream once; time goes to instruction issue on partly filled wavefronts and to exposed latency "
+                       "(useful_lane_frac, wave_instr_per_segment, wait_frac)")
+    roof["infinity_cache"] = ("rocprofv3 exposes no MALL hit counter on gfx950 (profiles/r03_rocprof_avail.txt); FETCH_SIZE counts "
+                              "L2 misses whether the Infinity Cache or HBM serves them, so frac is an upper bound of the HBM share")
+    if gen_ms > 0 and c.get("gen_kernel"):
+        g = kernel_block(c["gen_kernel"], gen_ms)
         # the generator's own floor: the 156 + 4 sequential 64-bit multiply-adds per ray that seeding
-        # std::mt19937_64 imposes (6 VALU each, 3 of them quarter-rate multiplies), priced against the
-        # measured rate of exactly that chain (tools/issue_ceiling.py kind 2: ~0.041 steps per SIMD-cycle)
+        # std::mt19937_64 imposes, priced against the measured rate of exactly that chain (tools/issue_ceiling.py)
         ceil = (cj.get("issue_ceiling") or {}).get("mt19937_64_seed_step@8w")
-        if ceil:
-            steps = rays / 64.0 * 160.0
-            g["mt_seed_step_frac"] = round(steps / (gen_ms * 1e-3) / (ceil * SIMDS * CLOCK_HZ), 4)
+        if ceil and rays:
+            g["mt_seed_step_frac"] = round(rays / 64.0 * 160.0 / (gen_ms * 1e-3) / (ceil * SIMDS * CLOCK_HZ), 4)
         roof["gen_kernel"] = g
     if cj.get("issue_ceiling"):
-        roof["measured_ceilings_per_simd_cycle"] = cj["issue_ceiling"]
+        roof["measured_issue_ceilings_per_simd_cycle"] = cj["issue_ceiling"]
     return roof
 
 
@@ -540,10 +587,14 @@ def cpu_baseline(pts, nrm, grid_delta, sticking, seed, sample_rays, total_rays, 
     o.set_rng_seed(seed)
     o.apply(cores)
     info = o.info()
-    return o, dict(value=sample_rays / info["time"] / 1e6, unit="Mrays/s", cores=cores, kind="port",
+    rate = sample_rays / info["time"] / 1e6
+    return o, dict(value=rate, unit="Mrays/s", cores=cores, kind="port",
                    sample=f"first {sample_rays} rays of the same {total_rays}-ray C2 workload, one thread per CPU "
-                          f"of this process's share ({cores}; OpenMP guided,64), oracle setup {t_setup:.1f}s excluded",
-                   seconds=info["time"])
+                          f"of this process's share ({cores}; OpenMP guided,64); `value` is the ray loop alone, "
+                          f"`value_incl_build` prices the whole {total_rays}-ray job with the oracle's scene build "
+                          f"({t_setup:.2f} s: BVH + neighbourhood) inside the timer like the reference (SURVEY Q10)",
+                   seconds=info["time"], setup_seconds=t_setup,
+                   value_incl_build=total_rays / (total_rays / (rate * 1e6) + t_setup) / 1e6)
 
 
 # ---------------------------------------------------------------------------------------------

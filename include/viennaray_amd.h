@@ -47,8 +47,12 @@ enum { VR_NORM_SOURCE = 0, VR_NORM_MAX = 1 };
  * 2        CONED_COSINE: surfaceReflection = ReflectionConedCosine(coneAngle) (rayReflection.hpp:52-120),
  *          collision like SpecularParticle
  * 3        DIFFUSE_COSINE: a DiffuseParticle with TWO data labels: label 0 += w, label 1 += w * max(0, -d.n)
- * A user model is added to the registry (a struct of __device__ functions) and gets the next id. */
-enum { VR_PARTICLE_DIFFUSE = 0, VR_PARTICLE_SPECULAR = 1, VR_PARTICLE_CONED_COSINE = 2, VR_PARTICLE_DIFFUSE_COSINE = 3 };
+ * 4        COVERAGE_STICKING: a DiffuseParticle whose sticking falls with the coverage of the primitive it meets:
+ *          sticking * (1 - globalData.vector(params[0])[primID]) — reads Trace::setGlobalData (vr_set_global_data)
+ * A model is a struct of __device__ functions {sticking, reflect, collide} appended to the registry's type list;
+ * its position is its id, its parameters travel in vr_particle::params. */
+enum { VR_PARTICLE_DIFFUSE = 0, VR_PARTICLE_SPECULAR = 1, VR_PARTICLE_CONED_COSINE = 2, VR_PARTICLE_DIFFUSE_COSINE = 3,
+       VR_PARTICLE_COVERAGE_STICKING = 4 };
 /* geometry kinds (rayGeometry.hpp:9) */
 enum { VR_GEOMETRY_DISK = 0, VR_GEOMETRY_TRIANGLE = 1 };
 
@@ -88,6 +92,7 @@ typedef struct vr_particle {
   const float *materialSticking;    /* ... -> sticking override               */
   float coneAngle;                  /* CONED_COSINE: maxConeAngle in radians  */
   float meanFreePath;               /* getMeanFreePath(); <= 0: no scattering (rayParticle.hpp:113) */
+  float params[8];                  /* the model's own parameters (registry models beyond the built-ins)      */
 } vr_particle;
 
 /* ---- life cycle (Trace::Trace / ~Trace, rayTrace.hpp:17-29) ------------- */
@@ -117,6 +122,16 @@ int vr_set_boundary_conditions(vr_context *ctx, const int32_t *bcs, int n /* = D
 int vr_set_source_direction(vr_context *ctx, int traceDirection);
 int vr_set_primary_direction(vr_context *ctx, const float *dir3 /* NULL = off */);
 int vr_set_particle(vr_context *ctx, const vr_particle *particle);
+/* Several particles in ONE apply(), as the reference's gpu::Trace does (gpu/raygTrace.hpp:163-248: one launch per
+ * particle, all with the seed of that apply): particle i's data labels follow particle i-1's in
+ * vr_get_flux_data / vr_num_data; particles with the same source distribution share one generator pass (the rays
+ * of ray index idx are the same for them).  runNumber advances once.                                         */
+int vr_set_particles(vr_context *ctx, const vr_particle *particles, uint32_t n);
+/* Trace::setGlobalData (rayTrace.hpp:137-145; handed to every surfaceCollision / surfaceReflection,
+ * rayParticle.hpp:21-81): vector `vecIdx` (indexed by primitive id) and the scalars of the caller's TracingData,
+ * copied to HBM and readable by the device particle models.  data == NULL drops the vector and those behind it. */
+int vr_set_global_data(vr_context *ctx, uint32_t vecIdx, const float *data, uint32_t n);
+int vr_set_global_scalars(vr_context *ctx, const float *data, uint32_t n);
 /* VIENNARAY_USE_WDIST (CMakeLists.txt:15, rayTraceKernel.hpp:258-296) as a run-time switch: a hit's
  * weight is shared among the credited disks by inverse impact distance                       */
 int vr_set_use_wdist(vr_context *ctx, int on);
@@ -182,6 +197,8 @@ int vr_get_flux_f64(vr_context *ctx, double *out, uint32_t n);
 uint32_t vr_num_data(const vr_context *ctx);
 int vr_get_flux_data(vr_context *ctx, uint32_t dataIdx, float *out, uint32_t n);
 int vr_get_trace_info(const vr_context *ctx, vr_trace_info *out);
+/* the counters of particle `particleIdx` of a multi-particle apply (vr_get_trace_info holds their sums)   */
+int vr_get_particle_trace_info(const vr_context *ctx, uint32_t particleIdx, vr_trace_info *out);
 /* which trace_kernel variant the last vr_apply_prepare selected: 0 general (reflection, roulette,
  * RNG), 1 absorbing + flat scene, 2 absorbing + structured scene, 3 general + flat scene,
  * 4 general, scene of a few hundred primitives resident in LDS             */

@@ -811,6 +811,42 @@ public:
   }
 };
 
+// The pattern `globalData` exists for (ViennaPS surface models): a diffuse particle whose sticking falls with the coverage
+// of the primitive it meets.  coverage = vector `coverageVector` of the TracingData given to Trace::setGlobalData.
+template <typename NumericType, int D>
+class CoverageStickingParticle : public Particle<CoverageStickingParticle<NumericType, D>, NumericType> {
+  const NumericType stickingProbability_;
+  const std::string dataLabel_;
+  const int coverageVector_;
+
+public:
+  CoverageStickingParticle(NumericType stickingProbability, std::string dataLabel, int coverageVector = 0)
+      : stickingProbability_(stickingProbability), dataLabel_(std::move(dataLabel)), coverageVector_(coverageVector) {}
+  std::pair<NumericType, Vec3D<NumericType>> surfaceReflection(NumericType, const Vec3D<NumericType> &,
+                                                               const Vec3D<NumericType> &geomNormal,
+                                                               const unsigned int primID, const int,
+                                                               const TracingData<NumericType> *globalData,
+                                                               RNG &rngState) final {
+    NumericType coverage = 0;
+    if (globalData && coverageVector_ < (int)globalData->getVectorData().size() &&
+        primID < globalData->getVectorData(coverageVector_).size())
+      coverage = globalData->getVectorData(coverageVector_)[primID];
+    return {stickingProbability_ * (NumericType(1) - coverage), ReflectionDiffuse<NumericType, D>(geomNormal, rngState)};
+  }
+  void surfaceCollision(NumericType rayWeight, const Vec3D<NumericType> &, const Vec3D<NumericType> &,
+                        const unsigned int primID, const int, TracingData<NumericType> &localData,
+                        const TracingData<NumericType> *, RNG &) final {
+    localData.getVectorData(0)[primID] += rayWeight;
+  }
+  NumericType getSourceDistributionPower() const final { return 1.; }
+  [[nodiscard]] std::vector<std::string> getLocalDataLabels() const final { return {dataLabel_}; }
+  bool deviceModel(vr_particle &pod) const final {
+    pod = vr_particle{VR_PARTICLE_COVERAGE_STICKING, (float)stickingProbability_, 1.f, 0, nullptr, nullptr, 0.f, -1.f, {}};
+    pod.params[0] = (float)coverageVector_;
+    return true;
+  }
+};
+
 // ---- Trace<T,D> ----------------------------------------------------------------------
 template <class NumericType, int D> class Trace {
 public:
@@ -848,6 +884,7 @@ public:
     }
     if (pSource_ && !sourceOnDevice_ && !uploadHostSource())
       return;
+    uploadGlobalData();
     const int rc = world_ > 1 ? vr_apply_sharded(ctx_, rank_, world_, reduce_, reduceUser_) : vr_apply(ctx_);
     vr_trace_info i{};
     vr_get_trace_info(ctx_, &i);
@@ -865,8 +902,12 @@ public:
       std::cerr << vr_last_error(ctx_) << "\n";
       return;
     }
-    // rayTraceDisk.hpp:40-47: one vector per data label of the particle
+    // rayTraceDisk.hpp:40-47: one vector per data label of the particle (of every particle of a list, in order)
     auto labels = pParticle_->getLocalDataLabels();
+    for (const auto &extra : moreParticles_) {
+      auto l = extra->getLocalDataLabels();
+      labels.insert(labels.end(), l.begin(), l.end());
+    }
     localData_.setNumberOfVectorData((int)labels.size());
     const uint32_t n = vr_num_primitives(ctx_);
     const uint32_t nd = vr_num_data(ctx_);
@@ -889,10 +930,31 @@ public:
             std::enable_if_t<std::is_base_of_v<AbstractParticle<NumericType>, ParticleType>, bool> = true>
   void setParticleType(std::unique_ptr<ParticleType> const &particle) {
     pParticle_ = particle->clone();
+    moreParticles_.clear();
     vr_particle pod{};
     particleOnDevice_ = pParticle_->deviceModel(pod);
     if (ctx_ && particleOnDevice_)
       check(vr_set_particle(ctx_, &pod));
+  }
+  /// NOT in the reference's CPU Trace (its gpu::Trace keeps a particle list, gpu/raygTrace.hpp:163-248): several
+  /// particles traced in ONE apply() — the same seed for all, one generator pass per source distribution;
+  /// getLocalData() holds particle 0's data labels, then particle 1's, ...; getRayTraceInfo() their summed counters.
+  void setParticleTypes(const std::vector<std::unique_ptr<AbstractParticle<NumericType>>> &particles) {
+    if (particles.empty())
+      return;
+    std::vector<vr_particle> pods(particles.size());
+    moreParticles_.clear();
+    particleOnDevice_ = true;
+    for (size_t q = 0; q < particles.size(); ++q) {
+      auto copy = particles[q]->clone();
+      particleOnDevice_ = copy->deviceModel(pods[q]) && particleOnDevice_;
+      if (q == 0)
+        pParticle_ = std::move(copy);
+      else
+        moreParticles_.push_back(std::move(copy));
+    }
+    if (ctx_ && particleOnDevice_)
+      check(vr_set_particles(ctx_, pods.data(), (uint32_t)pods.size()));
   }
 
   void setBoundaryConditions(BoundaryCondition boundaryConditions[D]) {
@@ -989,8 +1051,8 @@ public:
   }
 
   [[nodiscard]] TracingData<NumericType> &getLocalData() { return localData_; }
-  // rayTrace.hpp:137-145: global data is a borrowed pointer handed to user particles; the
-  // built-in particles never read it
+  // rayTrace.hpp:137-145: global data is a borrowed pointer handed to user particles; apply() copies its vectors and
+  // scalars to the device, where the registry's particle models read them (ModelCtx::global)
   [[nodiscard]] TracingData<NumericType> *getGlobalData() { return pGlobalData_; }
   void setGlobalData(TracingData<NumericType> &data) { pGlobalData_ = &data; }
   [[nodiscard]] TraceInfo getRayTraceInfo() const { return RTInfo_; }
@@ -1009,6 +1071,26 @@ protected:
   void geometryAccepted(int rc) { // a new geometry clears an earlier refusal
     setterError_ = false;
     check(rc);
+  }
+  // rayTrace.hpp:137-145: the borrowed global data may have changed since the last apply — its vectors and scalars
+  // go to HBM again (they are what the device particle models read; a few MB at most)
+  void uploadGlobalData() {
+    if (!ctx_)
+      return;
+    check(vr_set_global_data(ctx_, 0, nullptr, 0));
+    check(vr_set_global_scalars(ctx_, nullptr, 0));
+    if (!pGlobalData_)
+      return;
+    const auto &vecs = pGlobalData_->getVectorData();
+    for (size_t v = 0; v < vecs.size() && v < 16; ++v) {
+      std::vector<float> tmp(vecs[v].begin(), vecs[v].end());
+      if (!tmp.empty())
+        check(vr_set_global_data(ctx_, (uint32_t)v, tmp.data(), (uint32_t)tmp.size()));
+    }
+    const auto &sc = pGlobalData_->getScalarData();
+    std::vector<float> st(sc.begin(), sc.end());
+    if (!st.empty())
+      check(vr_set_global_scalars(ctx_, st.data(), (uint32_t)st.size()));
   }
   // A user Source is a host callback (raySource.hpp:10-19): evaluate it for every ray of the coming
   // apply() exactly as the reference's loop would (rayTraceKernel.hpp:118-140: engine seeded with
@@ -1085,6 +1167,7 @@ protected:
 
   vr_context *ctx_ = nullptr;
   std::unique_ptr<AbstractParticle<NumericType>> pParticle_ = nullptr;
+  std::vector<std::unique_ptr<AbstractParticle<NumericType>>> moreParticles_; // setParticleTypes: particles 1 ..
   TracingData<NumericType> localData_;
   TracingData<NumericType> *pGlobalData_ = nullptr;
   DataLog<NumericType> dataLog_;

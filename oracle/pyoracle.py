@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libvr_oracle.so")
 
-DIFFUSE, SPECULAR, CONED_COSINE, DIFFUSE_COSINE = 0, 1, 2, 3
+DIFFUSE, SPECULAR, CONED_COSINE, DIFFUSE_COSINE, COVERAGE_STICKING = 0, 1, 2, 3, 4
 REFLECTIVE, PERIODIC, IGNORE = 0, 1, 2
 POS_X, NEG_X, POS_Y, NEG_Y, POS_Z, NEG_Z = range(6)
 
@@ -51,6 +51,7 @@ def lib():
         L.orc_set_particle_ex.argtypes = [vp, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
         L.orc_set_material_sticking.argtypes = [vp, C.POINTER(C.c_int), fp, C.c_int]
         L.orc_set_wdist.argtypes = [vp, C.c_int]
+        L.orc_set_global_data.argtypes = [vp, C.c_uint, fp, C.c_uint]
         L.orc_set_source_grid.argtypes = [vp, fp, C.c_uint]
         L.orc_set_host_rays.argtypes = [vp, fp, fp, C.c_uint]
         L.orc_set_host_ray_weights.argtypes = [vp, fp, C.c_uint]
@@ -207,6 +208,14 @@ class Oracle:
         ids = (C.c_int * len(mapping))(*mapping.keys())
         vals = (C.c_float * len(mapping))(*mapping.values())
         self.L.orc_set_material_sticking(self.h, ids, vals, len(mapping))
+
+    def set_global_data(self, idx, data):
+        """Trace::setGlobalData: vector `idx` (None drops it)"""
+        if data is None:
+            self.L.orc_set_global_data(self.h, idx, None, 0)
+        else:
+            a = _f32(data)
+            self.L.orc_set_global_data(self.h, idx, _fp(a), a.size)
 
     def set_wdist(self, on=True):
         self.L.orc_set_wdist(self.h, int(on))

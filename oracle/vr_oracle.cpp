@@ -173,7 +173,10 @@ enum BoundaryCondition { REFLECTIVE = 0, PERIODIC = 1, IGNORE = 2 };
 // written against AbstractParticle the way a user (ViennaPS) writes them: CONED_COSINE reflects
 // with ReflectionConedCosine (rayReflection.hpp:52-120) and collects like SpecularParticle;
 // DIFFUSE_COSINE is a DiffuseParticle with TWO data labels: label 0 += w, label 1 += w * max(0, -d.n)
-enum ParticleKind { DIFFUSE = 0, SPECULAR = 1, CONED_COSINE = 2, DIFFUSE_COSINE = 3 };
+// COVERAGE_STICKING is the ViennaPS pattern globalData exists for (rayParticle.hpp:44-50 hands
+// `const TracingData *globalData` to surfaceReflection): a DiffuseParticle returning
+// {sticking * (1 - globalData->getVectorData(v)[primID]), ReflectionDiffuse}
+enum ParticleKind { DIFFUSE = 0, SPECULAR = 1, CONED_COSINE = 2, DIFFUSE_COSINE = 3, COVERAGE_STICKING = 4 };
 enum GeoType { DISK = 0, TRIANGLE = 1 };
 
 struct TraceInfo {
@@ -731,6 +734,8 @@ struct Context {
   // particle plug-ins beyond the two built-ins: what a user-defined
   // AbstractParticle (rayParticle.hpp:21-81) typically overrides
   float coneAngle = 0.f;    // CONED: surfaceReflection = ReflectionConedCosine(maxConeAngle)
+  int coverageVector = 0;   // COVERAGE_STICKING: index of the global vector read as coverage
+  std::vector<std::vector<float>> globalVecs; // Trace::setGlobalData (rayTrace.hpp:137-145): vectors by primitive id
   float meanFreePath = -1.f; // getMeanFreePath(); <= 0: no scattering (rayParticle.hpp:113)
   std::vector<std::pair<int, float>> materialSticking; // gpu::Particle::materialSticking (rayParticle.hpp:208-218)
   bool useWdist = false;    // VIENNARAY_USE_WDIST (rayTraceKernel.hpp:258-296), a run-time switch here
@@ -1416,7 +1421,7 @@ static void traceRay(Context &c, long long idx, unsigned seed, float *flux,
     // surfaceReflection (rayParticle.hpp:137-146,178-187) — called even when
     // sticking == 1
     Vec3 newDir;
-    if (c.particleKind == DIFFUSE || c.particleKind == DIFFUSE_COSINE)
+    if (c.particleKind == DIFFUSE || c.particleKind == DIFFUSE_COSINE || c.particleKind == COVERAGE_STICKING)
       newDir = ReflectionDiffuse(D, geomNormal, rngState);
     else if (c.particleKind == CONED_COSINE)
       newDir = ReflectionConedCosine(D, rayDirection, geomNormal, rngState, c.coneAngle);
@@ -1429,6 +1434,12 @@ static void traceRay(Context &c, long long idx, unsigned seed, float *flux,
       for (const auto &ms : c.materialSticking)
         if (ms.first == mat)
           sticking = ms.second;
+    }
+    if (c.particleKind == COVERAGE_STICKING) { // globalData->getVectorData(v)[primID]; a missing vector reads as 0
+      float coverage = 0.f;
+      if ((size_t)c.coverageVector < c.globalVecs.size() && hit.primID < c.globalVecs[c.coverageVector].size())
+        coverage = c.globalVecs[c.coverageVector][hit.primID];
+      sticking = sticking * (1.f - coverage);
     }
 
     rayWeight -= rayWeight * sticking;
@@ -1697,8 +1708,9 @@ void orc_set_particle(Context *c, int kind, float sticking, float sourcePower) {
 void orc_set_particle_ex(Context *c, int kind, float sticking, float sourcePower, float coneAngle, float meanFreePath) {
   c->particleKind = kind;
   c->sticking = sticking;
-  c->sourcePower = (kind == orc::DIFFUSE || kind == orc::DIFFUSE_COSINE) ? 1.f : sourcePower;
+  c->sourcePower = (kind == orc::DIFFUSE || kind == orc::DIFFUSE_COSINE || kind == orc::COVERAGE_STICKING) ? 1.f : sourcePower;
   c->coneAngle = coneAngle;
+  c->coverageVector = kind == orc::COVERAGE_STICKING ? (int)coneAngle : 0; // (the model's params[0])
   c->meanFreePath = meanFreePath;
 }
 void orc_set_material_sticking(Context *c, const int *ids, const float *vals, int n) {
@@ -1707,6 +1719,17 @@ void orc_set_material_sticking(Context *c, const int *ids, const float *vals, in
     c->materialSticking.emplace_back(ids[i], vals[i]);
 }
 void orc_set_wdist(Context *c, int on) { c->useWdist = on != 0; }
+// Trace::setGlobalData: vector `idx` of the borrowed TracingData (n == 0 drops it and those behind it)
+void orc_set_global_data(Context *c, unsigned idx, const float *data, unsigned n) {
+  if (n == 0) {
+    if (idx < c->globalVecs.size())
+      c->globalVecs.resize(idx);
+    return;
+  }
+  if (c->globalVecs.size() <= idx)
+    c->globalVecs.resize(idx + 1);
+  c->globalVecs[idx].assign(data, data + n);
+}
 // SourceGrid (raySourceGrid.hpp): explicit origins; n == 0 restores SourceRandom
 void orc_set_source_grid(Context *c, const float *pts, unsigned n) {
   c->sourceGrid.clear();

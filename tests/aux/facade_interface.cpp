@@ -61,7 +61,7 @@ public:
 // Every public method of Trace / TraceDisk that SURVEY.md 8(b) lists, once, on a flat 21 x 21 cloud (the plane of the
 // reference's tests/traceInterface: 441 points x 10 rays per point = 4410 rays, its one known answer).
 static void api_walk(TraceDisk<float, 3> &tracer, const std::vector<Vec3D<float>> &cloud,
-                     const std::vector<Vec3D<float>> &cloudNormals, float delta) {
+                     const std::vector<Vec3D<float>> &cloudNormals, float delta, TracingData<float> &global) {
   using T = float;
   // configuration first, geometry last: the setters are order independent
   tracer.setUseRandomSeeds(false);
@@ -112,7 +112,7 @@ static void api_walk(TraceDisk<float, 3> &tracer, const std::vector<Vec3D<float>
   const std::vector<T> third = tracer.getLocalData().getVectorData(0);
   VC_TEST_ASSERT(second != third);
   // borrowed global data comes back as it went in; the data log is reachable
-  TracingData<T> global;
+  // (the tracer keeps the POINTER, rayTrace.hpp:141: the data must outlive the applies that follow — main owns it)
   global.setNumberOfVectorData(1);
   global.setVectorData(0, cloud.size(), T(0.25), "coverage");
   tracer.setGlobalData(global);
@@ -128,8 +128,9 @@ int main() {
   std::vector<VectorType<NumericType, D>> points, normals;
   rayInternal::createPlaneGrid(gridDelta, extent, {0, 1, 2}, points, normals);
   VC_TEST_ASSERT(points.size() == 441);
+  TracingData<NumericType> globalData; // (declared before the tracer that borrows it)
   TraceDisk<NumericType, D> rayTracer;
-  api_walk(rayTracer, points, normals, gridDelta);
+  api_walk(rayTracer, points, normals, gridDelta, globalData);
 
   { // host-callback source: every ray comes straight down at y = 0.3 -> only the disks under that line
     rayTracer.setRngSeed(7);
@@ -178,6 +179,59 @@ int main() {
                                                                                    NumericType(0.5), "flux"));
     rayTracer.apply();
     VC_TEST_ASSERT(!rayTracer.getRayTraceInfo().error && rayTracer.getRayTraceInfo().reflections > 0);
+  }
+  { // global data on the device.  A floor with a wall on it, so that reflected rays meet the surface again: coverage 1
+    // everywhere = sticking 0 = a ray keeps its whole weight for the next hit; coverage 0 = plain sticking 0.5
+    std::vector<VectorType<NumericType, D>> cornerPts = points, cornerNrm = normals;
+    for (NumericType y = -extent; y <= extent; y += gridDelta)
+      for (NumericType z = gridDelta; z <= NumericType(3); z += gridDelta) {
+        cornerPts.push_back({NumericType(-2), y, z});
+        cornerNrm.push_back({NumericType(1), NumericType(0), NumericType(0)});
+      }
+    TraceDisk<NumericType, D> corner;
+    TracingData<NumericType> coverage; // (outlives the applies below: the tracer keeps the pointer)
+    coverage.setNumberOfVectorData(1);
+    coverage.setVectorData(0, cornerPts.size(), NumericType(1), "coverage");
+    corner.setGeometry(cornerPts, cornerNrm, gridDelta);
+    BoundaryCondition mirrors[D] = {BoundaryCondition::REFLECTIVE_BOUNDARY, BoundaryCondition::REFLECTIVE_BOUNDARY,
+                                    BoundaryCondition::REFLECTIVE_BOUNDARY};
+    corner.setBoundaryConditions(mirrors);
+    corner.setNumberOfRaysPerPoint(20);
+    corner.setRngSeed(3);
+    corner.setGlobalData(coverage);
+    corner.setParticleType(std::make_unique<CoverageStickingParticle<NumericType, D>>(NumericType(0.5), "flux", 0));
+    auto total = [&] {
+      corner.setRngSeed(3); // (the seed is rngSeed + runNumber, and apply() advances runNumber)
+      corner.apply();
+      double s = 0;
+      for (auto v : corner.getLocalData().getVectorData("flux"))
+        s += v;
+      return s;
+    };
+    const double covered = total();
+    const auto infoCovered = corner.getRayTraceInfo();
+    for (auto &v : coverage.getVectorData(0))
+      v = NumericType(0);
+    const double bare = total(); // (the borrowed data changed between the applies: it is uploaded again)
+    VC_TEST_ASSERT(!infoCovered.error && !corner.getRayTraceInfo().error && infoCovered.reflections > infoCovered.numRays / 2);
+    VC_TEST_ASSERT(covered > bare * 1.02);
+    std::printf("coverage sticking: %g credited fully covered, %g bare\n", covered, bare);
+  }
+  { // a particle list in one apply: the labels of all particles, in order
+    std::vector<std::unique_ptr<AbstractParticle<NumericType>>> list;
+    list.push_back(std::make_unique<DiffuseParticle<NumericType, D>>(NumericType(0.2), "neutral"));
+    list.push_back(std::make_unique<SpecularParticle<NumericType, D>>(NumericType(0.9), NumericType(20), "ion"));
+    rayTracer.setParticleTypes(list);
+    rayTracer.apply();
+    auto &ld = rayTracer.getLocalData();
+    VC_TEST_ASSERT(!rayTracer.getRayTraceInfo().error && ld.getVectorDataIndex("neutral") == 0 && ld.getVectorDataIndex("ion") == 1);
+    double a = 0, b = 0;
+    for (auto v : ld.getVectorData("neutral"))
+      a += v;
+    for (auto v : ld.getVectorData("ion"))
+      b += v;
+    VC_TEST_ASSERT(a > 0 && b > 0 && a != b);
+    std::printf("particle list: sum neutral %g, sum ion %g\n", a, b);
   }
   { // a host-only user particle is refused, loudly
     rayTracer.setParticleType(std::make_unique<HostOnlyParticle<NumericType>>());

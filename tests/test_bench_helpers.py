@@ -24,3 +24,20 @@ def test_algorithmic_bytes_match_survey():
 def test_host_cpu_share_is_sane():
     n = _bench().host_cpu_share()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_roofline_block_is_counter_bytes_over_time_over_peak():
+    """roofline.frac = (2 FETCH_SIZE + WRITE_SIZE) KiB per launch / kernel time / 8 TB/s (round-2 verdict, item 2), with the
+    useful-work figures beside it; the issue figures are diagnostics, never the fraction."""
+    b = _bench()
+    k = dict(name="vr::trace_kernel<3, 0, 0, 1>", avg_ms=6.5, FETCH_SIZE=4.0e6, WRITE_SIZE=1.0e6, hbm_bytes=(2 * 4.0e6 + 1.0e6) * 1024,
+             l2_hit_rate=0.74, useful_lane_frac=0.34, lanes_per_valu_instr=48.5, SQ_WAIT_ANY_frac=0.52,
+             SQ_INSTS_VALU=3.0e9, SQ_INSTS_SALU=2.0e9, SQ_INSTS_SMEM=1e7, SQ_INSTS_VMEM_RD=8e7, SQ_INSTS_VMEM_WR=2e7, SQ_INSTS_LDS=6e7)
+    r = b.kernel_block(k, ms=6.0, segments=1.0e8)
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert r["traffic"] == int(9.0e6 * 1024)
+    assert abs(r["achieved"] - 9.0e6 * 1024 / 6.0e-3 / 1e9) < 0.1
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4 and r["frac"] < 1.0
+    assert abs(r["wave_instr_per_segment"] - 51.7) < 0.1
+    assert r["useful_lane_frac"] == 0.34 and r["l2_hit_rate"] == 0.74 and r["wait_frac"] == 0.52
+    assert "issue_diag" in r and "frac" not in r["issue_diag"]

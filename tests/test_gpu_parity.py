@@ -1259,6 +1259,140 @@ def test_two_label_particle_matches_oracle(geom):
     assert (ld.getVectorData("flux") >= a - 1e-3).all()      # cos <= 1
 
 
+@pytest.mark.parametrize("geom", ["trench3d", "mesh", "trench2d", "plane"])
+def test_coverage_dependent_sticking_reads_global_data(geom):
+    """globalData on the device (rayParticle.hpp:21-81 hands `const TracingData *globalData` to every callback;
+    rayTrace.hpp:141): the registry's CoverageStickingParticle sticks with s0 * (1 - coverage[primID]), coverage =
+    vector 1 of the caller's global data (vector 0 is a decoy) — every counter and the flux against the oracle."""
+    if geom == "plane":   # a flat scene: MODE 3, the packet query's crediting of registry particles
+        pts, nrm = vr.io.plane_grid(60, 1.0)
+        t = vr.TraceDisk(3)
+        t.setGeometry(pts, nrm, 1.0)
+        t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+        o = po.Oracle()
+        o.set_disks(pts, nrm, 1.0, 3)
+        o.set_boundary_conditions([po.PERIODIC] * 3)
+        t.setParticleType(vr.CoverageStickingParticle(0.6, "flux", coverageVector=1))
+        o.set_particle_ex(po.COVERAGE_STICKING, 0.6, 1.0, 1.0, -1.0)   # (4th argument: the model's params[0])
+        for x, m in ((t, "setNumberOfRaysPerPoint"), (o, "set_num_rays_per_point")):
+            getattr(x, m)(300)
+        t.setRngSeed(4242)
+        o.set_rng_seed(4242)
+        o.set_lazy_rng(True)
+    else:
+        t, o = _plugin_pair(geom, vr.CoverageStickingParticle(0.6, "flux", coverageVector=1), po.COVERAGE_STICKING, 0.6,
+                            cone=1.0)
+    n = t._n
+    rng = np.random.default_rng(17)
+    decoy = rng.uniform(0, 1, n).astype(np.float32)
+    coverage = rng.uniform(0, 1, n).astype(np.float32)
+    coverage[::7] = 1.0      # fully covered: sticking 0, the ray keeps its whole weight
+    coverage[3::11] = 0.0
+    g = vr.TracingData()
+    g.setNumberOfVectorData(2)
+    g.setVectorData(0, decoy, "decoy")
+    g.setVectorData(1, coverage, "coverage")
+    t.setGlobalData(g)
+    assert t.getGlobalData() is g
+    o.set_global_data(0, decoy)
+    o.set_global_data(1, coverage)
+    err, gi = compare(t, o)
+    assert gi["reflections"] > gi["geometryHits"] // 2
+    if geom == "plane":
+        assert t.traceMode() == 3
+    f_cov = t.getFluxF64()
+    # without global data the model reads coverage 0: plain sticking 0.6 — the DiffuseParticle's flux, and a different
+    # one wherever a ray can meet the surface twice (on the plane every reflected ray leaves: nothing to see there)
+    t.setGlobalData([])
+    t.setRunNumber(1)
+    t.apply()
+    assert geom == "plane" or l2_rel(t.getFluxF64(), f_cov) > 1e-3
+    o.set_global_data(0, None)
+    o.set_run_number(1)
+    o.apply(po.max_threads())
+    assert l2_rel(t.getLocalData().getVectorData(0), o.flux()) <= 5e-6
+
+
+@pytest.mark.parametrize("geom", ["trench3d", "plane", "trench2d", "mesh"])
+def test_multi_particle_apply_shares_the_generator_pass(geom):
+    """Several particles in ONE apply() (gpu/raygTrace.hpp:163-248: one launch per particle, all with the apply's seed).
+    Four particles — two with the source's cosine power 1 (one generator pass for both), an absorbing one, and a
+    specular one with power 8 — against four oracle runs with the same run number: every particle's counters and
+    every data label."""
+    plist = [(vr.DiffuseParticle(0.2, "a"), po.DIFFUSE, 0.2, 1.0), (vr.DiffuseCosineParticle(0.5, "b", "bcos"), po.DIFFUSE_COSINE, 0.5, 1.0),
+             (vr.DiffuseParticle(1.0, "c"), po.DIFFUSE, 1.0, 1.0), (vr.SpecularParticle(0.3, 8.0, "d"), po.SPECULAR, 0.3, 8.0)]
+    if geom == "plane":
+        pts, nrm = vr.io.plane_grid(70, 1.0)
+        t = vr.TraceDisk(3)
+        t.setGeometry(pts, nrm, 1.0)
+        t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+
+        def oracle():
+            o = po.Oracle()
+            o.set_disks(pts, nrm, 1.0, 3)
+            o.set_boundary_conditions([po.PERIODIC] * 3)
+            return o
+    else:
+        t, _ = _plugin_pair(geom, plist[0][0], plist[0][1], plist[0][2])
+
+        def oracle():
+            return _plugin_pair(geom, plist[0][0], plist[0][1], plist[0][2])[1]
+    t.setNumberOfRaysPerPoint(40)
+    t.setRngSeed(99)
+    t.setParticleTypes([q[0] for q in plist])
+    t.apply()
+    assert t.numData() == 5
+    ld = t.getLocalData()
+    labels = [ld.getVectorDataLabel(k) for k in range(5)]
+    assert labels == ["a", "b", "bcos", "c", "d"]
+    info = info_dict(t)
+    sums = {k: 0 for k in INFO_KEYS[1:]}
+    plane = 0
+    for q, (particle, okind, sticking, power) in enumerate(plist):
+        o = oracle()
+        o.set_particle_ex(okind, sticking, power, 0.0, -1.0)
+        o.set_num_rays_per_point(40)
+        o.set_rng_seed(99)
+        o.set_lazy_rng(True)
+        o.apply(po.max_threads())
+        pi = t.getParticleTraceInfo(q)
+        oi = o.info()
+        for k in INFO_KEYS:
+            assert int(getattr(pi, k)) == oi[k], (q, k)
+        for k in sums:
+            sums[k] += oi[k]
+        for l in range(o.num_data()):
+            assert l2_rel(ld.getVectorData(plane), o.flux_data(l)) <= 5e-6, (q, l)
+            plane += 1
+    assert {k: info[k] for k in sums} == sums       # getRayTraceInfo(): the sums over the particles
+    assert t.getRunNumber() == 2                     # ONE apply
+    # a single-particle apply afterwards is the plain path again
+    t.setParticleType(vr.DiffuseParticle(0.2, "a"))
+    t.setRunNumber(1)
+    t.apply()
+    assert t.numData() == 1 and (t.getLocalData().getVectorData("a") == ld.getVectorData(0)).all()
+
+
+def test_registry_particles_use_packet_query_crediting_on_flat_scenes(monkeypatch):
+    """the two-label particle on P(100): MODE 3 (packet-query crediting of registry particles) gives what MODE 0 gives"""
+    pts, nrm = vr.io.plane_grid(100, 1.0)
+
+    def run():
+        t = vr.TraceDisk(3)
+        t.setGeometry(pts, nrm, 1.0)
+        t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+        t.setParticleType(vr.DiffuseCosineParticle(0.3, "flux", "cos"))
+        t.setNumberOfRaysFixed(2_000_000)
+        t.setRngSeed(5)
+        t.apply()
+        return t.traceMode(), info_dict(t), t.getLocalData().getVectorData(0).copy(), t.getLocalData().getVectorData(1).copy()
+    m3, i3, a3, b3 = run()
+    monkeypatch.setenv("VR_GENERAL_FLAT", "0")
+    m0, i0, a0, b0 = run()
+    assert (m3, m0) == (3, 0) and i3 == i0
+    assert (a3 == a0).all() and l2_rel(b3, b0) <= 1e-6
+
+
 @pytest.mark.parametrize("geom", ["trench3d", "sphere", "trench2d"])
 def test_wdist_crediting_matches_oracle(geom):
     """VIENNARAY_USE_WDIST (rayTraceKernel.hpp:258-296): the hit's weight shared by inverse impact distance"""
@@ -1571,7 +1705,7 @@ def test_apply_sharded_ranks_sum_to_the_whole():
             t.setRunNumber(1)
             calls.clear()
             t.applySharded(rank, world, cb, None)
-            assert calls == [t._n, 64]   # the flux, then counters [0..7] together with the failure word [60]
+            assert calls == [t._n, 80]   # the flux, then the particle's counter block: [0..7] together with the failure word [60]
             parts.append(t.getFluxF64())
             infos.append(info_dict(t))
         assert (sum(parts) == whole).all()

@@ -53,9 +53,14 @@ if fixed:
 else:
     t.setNumberOfRaysPerPoint(rpp)
 t.setRngSeed(12345)
+import json
 for i in range(rep):
     t.setRunNumber(1)
     t.apply()
     info = t.getRayTraceInfo()
+    # (the JSON line is what tools/pmc_profile.py reads: rays and trace segments of one launch)
+    print(json.dumps(dict(vr_case=case, sticking=sticking, rays=int(info.numRays), segments=int(info.totalRaysTraced),
+                          device_ms=info.timeTrace * 1e3, trace_kernel_ms=info.timeTraceKernel * 1e3,
+                          gen_kernel_ms=info.timeGenKernel * 1e3, mode=t.traceMode())))
     print(f"{case} sticking {sticking}: rays {info.numRays} segments {info.totalRaysTraced} device {info.timeTrace*1e3:.2f} ms "
           f"trace_kernel {info.timeTraceKernel*1e3:.2f} ms -> {info.numRays/info.timeTrace/1e6:.0f} Mrays/s")

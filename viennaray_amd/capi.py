@@ -35,7 +35,8 @@ class TraceInfoPOD(C.Structure):
 class ParticlePOD(C.Structure):
     _fields_ = [("kind", C.c_int32), ("sticking", C.c_float), ("sourcePower", C.c_float),
                 ("numMaterialSticking", C.c_int32), ("materialIds", C.POINTER(C.c_int32)),
-                ("materialSticking", C.POINTER(C.c_float)), ("coneAngle", C.c_float), ("meanFreePath", C.c_float)]
+                ("materialSticking", C.POINTER(C.c_float)), ("coneAngle", C.c_float), ("meanFreePath", C.c_float),
+                ("params", C.c_float * 8)]
 
 
 # every symbol include/viennaray_amd.h declares: name -> (restype, argtypes)
@@ -57,6 +58,10 @@ SIGNATURES = {
     "vr_set_source_direction": (C.c_int, [_vp, C.c_int]),
     "vr_set_primary_direction": (C.c_int, [_vp, _fp]),
     "vr_set_particle": (C.c_int, [_vp, C.POINTER(ParticlePOD)]),
+    "vr_set_particles": (C.c_int, [_vp, C.POINTER(ParticlePOD), C.c_uint32]),
+    "vr_set_global_data": (C.c_int, [_vp, C.c_uint32, _fp, C.c_uint32]),
+    "vr_set_global_scalars": (C.c_int, [_vp, _fp, C.c_uint32]),
+    "vr_get_particle_trace_info": (C.c_int, [_vp, C.c_uint32, C.POINTER(TraceInfoPOD)]),
     "vr_set_use_wdist": (C.c_int, [_vp, C.c_int]),
     "vr_set_source_grid": (C.c_int, [_vp, _fp, C.c_uint32]),
     "vr_set_host_rays": (C.c_int, [_vp, _fp, _fp, _u32p, C.c_uint64]),

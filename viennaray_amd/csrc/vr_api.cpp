@@ -63,11 +63,29 @@ template <class T> struct DevBuf {
 };
 } // namespace
 
+// one entry of vr_set_particles (a deep copy of the caller's vr_particle)
+struct ParticleSpec {
+  int kind = 0;
+  float sticking = 1.f, sourcePower = 1.f, coneAngle = 0.f, meanFreePath = -1.f;
+  float params[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<int32_t> matIds;
+  std::vector<float> matVals;
+};
+// the prepared launch of one particle of a multi-particle apply()
+struct ParticleLaunch {
+  TraceParams params{};
+  unsigned grid = 0;
+  int traceMode = 0, kernelParticle = 0;
+  bool absorb = false;
+  uint32_t numData = 1, dataBase = 0;
+  float *primSticking = nullptr; // owned (hipMalloc): this particle's per-primitive sticking, leaf order
+  vr_trace_info info{};
+};
+
 struct vr_context {
   int device = 0;
   int numCUs = 256;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr; // generator / sorter stream (overlaps the tracer)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
 
@@ -88,8 +106,21 @@ struct vr_context {
   int particleKind = 0;
   float coneAngle = 0.f, meanFreePath = -1.f;
   bool useWdist = false;
-  uint32_t numData = 1;           // data labels of the particle (accumulator planes)
+  uint32_t numData = 1;           // data labels of the (active) particle
+  uint32_t totalData = 1;         // ... of all particles of the apply: accumulator planes, TracingData vectors
+  uint32_t dataBase = 0;          // first plane of the active particle
+  uint32_t counterSlot = 0;       // ... and its block of 80 counter words
   uint32_t accPlanes = 0;         // planes the accumulator buffers currently hold
+  float particleParams[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool particleDirty = true;      // the sticking map needs recomputing
+  std::vector<ParticleSpec> specs;      // vr_set_particles: > 1 entries = a multi-particle apply
+  std::vector<ParticleLaunch> launches; // prepared by vr_apply_prepare when specs.size() > 1
+  // Trace::setGlobalData: vectors (padded to one stride) and scalars, resident in HBM
+  std::vector<std::vector<float>> globalVecs;
+  std::vector<float> globalScalars;
+  bool globalDirty = false;
+  uint32_t globalStride = 0;
+  DevBuf<float> dGlobalVec, dGlobalScalars;
   // sources other than SourceRandom
   std::vector<float> gridPoints;  // SourceGrid origins (raySourceGrid.hpp)
   std::vector<float> hostOrg, hostDir;
@@ -109,7 +140,10 @@ struct vr_context {
   bool useRandomSeed = true;
   uint32_t runNumber = 1;
   uint64_t rayFirst = 0, rayCount = 0;
-  bool haveSharedSeed = false; // vr_apply_sharded + useRandomSeed: rank 0's draw, handed round by the all-reduce
+  bool haveSharedSeed = false; // vr_apply_sharded + useRandomSeed: rank 0's draw, handed round by the all-reduce;
+                               // a multi-particle apply with random seeds: its one draw
+  bool keepSharedSeed = false; // (the sharded entry point clears the seed itself)
+  size_t numGenLaunches = 0, numTraceLaunches = 0;
   uint32_t sharedSeed = 0;
 
   // derived at prepare()
@@ -133,7 +167,7 @@ struct vr_context {
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
   uint32_t nbTotal = 0;               // entries of the resident neighbourhood CSR
   DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
-  DevBuf<unsigned long long> dWorkQ;  // span cursors of the trace kernel's per-XCD queues (two sets: overlap mode)
+  DevBuf<unsigned long long> dWorkQ;  // span cursors of the trace kernel's per-XCD queues
   size_t scratchWaves = 0;
   // flux accumulators are replicated accReplicas times (power of two, stride accStride
   // elements); a block credits replica blockIdx & (accReplicas-1): small scenes would
@@ -164,12 +198,10 @@ struct vr_context {
   bool hostOrderValid = false;   // c->bvh.order mirrors dOrder
   bool hostNeighborsValid = false;
   // ray stream (one batch)
-  DevBuf<float> dSlotRec, dSlotRec2, dWalls;
-  DevBuf<uint32_t> dBinCount, dBinCount2;
+  DevBuf<float> dSlotRec, dWalls;
+  DevBuf<uint32_t> dBinCount;
   size_t slotStride = 0; // record slots of the ray-stream buffer (bins + overflow region)
   uint32_t raysPerBin = 40;
-  std::vector<hipEvent_t> evSort, evTraced; // per batch: sorted stream ready / trace finished
-  bool overlap = false;
   DevBuf<uint32_t> dScanTmp;
   uint32_t batchCap = 0;      // rays per batch the buffers hold
   uint32_t numBins = 0;
@@ -178,7 +210,6 @@ struct vr_context {
   std::vector<hipEvent_t> evK; // trace-kernel event pairs, one per batch
   std::vector<hipEvent_t> evG; // generator event pairs, one per batch
   double traceKernelSeconds = 0.0;
-  size_t numBatches = 0;
   bool havePrimSticking = false;
   unsigned long long *boundFlux = nullptr; // caller-owned accumulator buffer
   uint32_t boundFluxN = 0;
@@ -222,7 +253,6 @@ int vr_create(vr_context **out, int device) {
   vr_context *c = new vr_context();
   c->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return VR_E_HIP;
@@ -240,12 +270,9 @@ void vr_destroy(vr_context *c) {
   (void)hipSetDevice(c->device);
   if (c->stream)
     (void)hipStreamSynchronize(c->stream);
-  if (c->stream2)
-    (void)hipStreamSynchronize(c->stream2);
-  for (auto e : c->evSort)
-    (void)hipEventDestroy(e);
-  for (auto e : c->evTraced)
-    (void)hipEventDestroy(e);
+  for (auto &L : c->launches)
+    if (L.primSticking)
+      (void)hipFree(L.primSticking);
   c->dNodes.release();
   c->dPrims.release();
   c->dPrimSticking.release();
@@ -258,9 +285,7 @@ void vr_destroy(vr_context *c) {
   c->dScratch.release();
   c->dWalls.release();
   c->dSlotRec.release();
-  c->dSlotRec2.release();
   c->dBinCount.release();
-  c->dBinCount2.release();
   c->dScanTmp.release();
   for (auto e : c->evK)
     (void)hipEventDestroy(e);
@@ -272,8 +297,6 @@ void vr_destroy(vr_context *c) {
     (void)hipEventDestroy(c->ev1);
   if (c->stream)
     (void)hipStreamDestroy(c->stream);
-  if (c->stream2)
-    (void)hipStreamDestroy(c->stream2);
   delete c;
 }
 
@@ -353,25 +376,89 @@ int vr_set_primary_direction(vr_context *c, const float *d) {
   c->configDirty = true;
   return VR_OK;
 }
-int vr_set_particle(vr_context *c, const vr_particle *p) {
-  if (!c || !p || p->kind < VR_PARTICLE_DIFFUSE || p->kind > VR_PARTICLE_DIFFUSE_COSINE)
-    return fail(c, VR_E_INVALID, "vr_set_particle: unknown particle kind (not in the device registry)");
-  c->particleKind = p->kind;
-  c->sticking = p->sticking;
-  // rayParticle.hpp:158,199
-  c->sourcePower = (p->kind == VR_PARTICLE_DIFFUSE || p->kind == VR_PARTICLE_DIFFUSE_COSINE) ? 1.f : p->sourcePower;
-  c->coneAngle = p->coneAngle;
-  c->meanFreePath = p->meanFreePath;
-  c->numData = (uint32_t)Particles::numData(p->kind);
-  c->matStickIds.clear();
-  c->matStickVals.clear();
+static bool spec_from_pod(const vr_particle *p, ParticleSpec &sp) {
+  if (!p || p->kind < 0 || p->kind >= Particles::count)
+    return false;
+  sp = ParticleSpec{};
+  sp.kind = p->kind;
+  sp.sticking = p->sticking;
+  // rayParticle.hpp:158,199: only SpecularParticle-like particles carry a source power of their own
+  sp.sourcePower = (p->kind == VR_PARTICLE_DIFFUSE || p->kind == VR_PARTICLE_DIFFUSE_COSINE ||
+                    p->kind == VR_PARTICLE_COVERAGE_STICKING)
+                       ? 1.f
+                       : p->sourcePower;
+  sp.coneAngle = p->coneAngle;
+  sp.meanFreePath = p->meanFreePath;
+  std::memcpy(sp.params, p->params, sizeof(sp.params));
+  if (p->kind == VR_PARTICLE_CONED_COSINE)
+    sp.params[0] = p->coneAngle; // (the model reads its cone angle from params[0])
   if (p->numMaterialSticking > 0 && p->materialIds && p->materialSticking) {
-    c->matStickIds.assign(p->materialIds, p->materialIds + p->numMaterialSticking);
-    c->matStickVals.assign(p->materialSticking, p->materialSticking + p->numMaterialSticking);
+    sp.matIds.assign(p->materialIds, p->materialIds + p->numMaterialSticking);
+    sp.matVals.assign(p->materialSticking, p->materialSticking + p->numMaterialSticking);
   }
+  return true;
+}
+
+// make `sp` the particle the next prepare works on
+static void activate_particle(vr_context *c, const ParticleSpec &sp) {
+  c->particleKind = sp.kind;
+  c->sticking = sp.sticking;
+  c->sourcePower = sp.sourcePower;
+  c->coneAngle = sp.coneAngle;
+  c->meanFreePath = sp.meanFreePath;
+  std::memcpy(c->particleParams, sp.params, sizeof(sp.params));
+  c->numData = (uint32_t)Particles::numData(sp.kind);
+  c->matStickIds = sp.matIds;
+  c->matStickVals = sp.matVals;
+  c->particleDirty = true;
+}
+
+int vr_set_particles(vr_context *c, const vr_particle *list, uint32_t n) {
+  if (!c || !list || n == 0 || n > 64)
+    return fail(c, VR_E_INVALID, "vr_set_particles: between 1 and 64 particles");
+  std::vector<ParticleSpec> specs(n);
+  uint32_t total = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!spec_from_pod(&list[i], specs[i]))
+      return fail(c, VR_E_INVALID, "vr_set_particle: unknown particle kind (not in the device registry)");
+    total += (uint32_t)Particles::numData(specs[i].kind);
+  }
+  c->specs = std::move(specs);
+  activate_particle(c, c->specs[0]);
+  c->totalData = total;
+  c->dataBase = 0;
+  c->counterSlot = 0;
+  c->boundFlux = nullptr; // (the number of planes may have changed)
   c->haveParticle = true;
   c->prepared = false;
-  c->configDirty = true;
+  return VR_OK;
+}
+
+int vr_set_particle(vr_context *c, const vr_particle *p) { return vr_set_particles(c, p, 1); }
+
+// Trace::setGlobalData (rayTrace.hpp:137-145): vector `vecIdx` of the borrowed TracingData (data == NULL or n == 0
+// drops it and every vector behind it).  The particle models index it by the primitive id of the caller's geometry.
+int vr_set_global_data(vr_context *c, uint32_t vecIdx, const float *data, uint32_t n) {
+  if (!c || vecIdx >= 16 || (n && !data))
+    return fail(c, VR_E_INVALID, "vr_set_global_data: bad argument (at most 16 vectors)");
+  if (!data || n == 0) {
+    if (vecIdx < c->globalVecs.size())
+      c->globalVecs.resize(vecIdx);
+  } else {
+    if (c->globalVecs.size() <= vecIdx)
+      c->globalVecs.resize(vecIdx + 1);
+    c->globalVecs[vecIdx].assign(data, data + n);
+  }
+  c->globalDirty = true;
+  c->prepared = false;
+  return VR_OK;
+}
+int vr_set_global_scalars(vr_context *c, const float *data, uint32_t n) {
+  if (!c || (n && !data))
+    return fail(c, VR_E_INVALID, "vr_set_global_scalars: bad argument");
+  c->globalScalars.assign(data, data + n);
+  c->globalDirty = true;
+  c->prepared = false;
   return VR_OK;
 }
 int vr_set_use_wdist(vr_context *c, int on) {
@@ -795,9 +882,8 @@ static uint64_t rays_of_apply(const vr_context *c) {
   return c->numRaysFixed == 0 ? srcPoints * c->numRaysPerPoint : c->numRaysFixed;
 }
 
-int vr_apply_prepare(vr_context *c) {
-  if (!c)
-    return VR_E_INVALID;
+// everything one particle's launch needs (scene build and areas only when they changed)
+static int prepare_one(vr_context *c) {
   VR_HIP(c, hipSetDevice(c->device));
   c->info = vr_trace_info{};
   // checkSettings (rayTraceDisk.hpp:196-217): the reference logs and carries
@@ -900,9 +986,10 @@ int vr_apply_prepare(vr_context *c) {
     c->areasValid = true;
   }
   // per-primitive sticking from the material map (gpu::Particle-style, rayParticle.hpp:208-218)
-  if (redoConfig)
+  const bool redoSticking = redoConfig || c->particleDirty;
+  if (redoSticking)
     c->havePrimSticking = false;
-  if (redoConfig && !c->matStickIds.empty()) {
+  if (redoSticking && !c->matStickIds.empty()) {
     int ro = ensure_host_order(c);
     if (ro != VR_OK)
       return ro;
@@ -922,6 +1009,26 @@ int vr_apply_prepare(vr_context *c) {
   }
   const float *dStick = c->havePrimSticking ? c->dPrimSticking.p : nullptr;
   c->configDirty = false;
+  c->particleDirty = false;
+  // Trace::setGlobalData: every vector padded to one stride, one upload
+  if (c->globalDirty) {
+    uint32_t stride = 0;
+    for (const auto &v : c->globalVecs)
+      stride = std::max<uint32_t>(stride, (uint32_t)v.size());
+    c->globalStride = stride;
+    if (stride && !c->globalVecs.empty()) {
+      std::vector<float> flat((size_t)stride * c->globalVecs.size(), 0.f);
+      for (size_t v = 0; v < c->globalVecs.size(); ++v)
+        std::copy(c->globalVecs[v].begin(), c->globalVecs[v].end(), flat.begin() + v * stride);
+      VR_HIP(c, c->dGlobalVec.ensure(flat.size()));
+      VR_HIP(c, hipMemcpy(c->dGlobalVec.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (!c->globalScalars.empty()) {
+      VR_HIP(c, c->dGlobalScalars.ensure(c->globalScalars.size()));
+      VR_HIP(c, hipMemcpy(c->dGlobalScalars.p, c->globalScalars.data(), c->globalScalars.size() * 4, hipMemcpyHostToDevice));
+    }
+    c->globalDirty = false;
+  }
 
   const uint64_t numRays = rays_of_apply(c);
   c->numRaysLast = numRays;
@@ -952,7 +1059,7 @@ int vr_apply_prepare(vr_context *c) {
     c->absorb = false; // (the absorbing kernels credit unit weights)
   // (the rare, register-hungry options — coned-cosine model, WDIST crediting, mean free path — have an instantiation
   //  of their own: multi-label and per-material particles should not pay for them)
-  const bool extFull = c->particleKind == (int)P_CONED_COSINE || c->useWdist || c->meanFreePath > 0.f;
+  const bool extFull = Particles::needsFull(c->particleKind) || c->useWdist || c->meanFreePath > 0.f;
   c->kernelParticle = extended ? (extFull ? (int)P_EXT_FULL : (int)P_EXT) : c->particleKind;
   // a scene of a few hundred primitives goes into LDS as a whole (MODE 4: the general kernel — also for
   // absorbing particles — of whatever particle): pair nodes, records, neighbourhood, accumulators (one plane
@@ -984,12 +1091,12 @@ int vr_apply_prepare(vr_context *c) {
       c->absorb = false; // (ray records with the RNG cursors: the general kernel reads them)
   }
   // accumulators: one plane per data label, each replicated accReplicas times
-  if (c->accPlanes != c->numData) {
-    VR_HIP(c, c->dFluxAcc.ensure((size_t)c->accStride * c->accReplicas * c->numData));
-    VR_HIP(c, c->dFluxOrig.ensure((size_t)N * c->numData));
-    c->accPlanes = c->numData;
+  if (c->accPlanes != c->totalData) {
+    VR_HIP(c, c->dFluxAcc.ensure((size_t)c->accStride * c->accReplicas * c->totalData));
+    VR_HIP(c, c->dFluxOrig.ensure((size_t)N * c->totalData));
+    c->accPlanes = c->totalData;
   }
-  if (c->boundFlux && c->boundFluxN != N * c->numData)
+  if (c->boundFlux && c->boundFluxN != N * c->totalData)
     return fail(c, VR_E_STATE, "bound accumulator buffer does not hold numPrims x numData int64");
   // source data
   if (c->sourceDirty) {
@@ -1014,20 +1121,16 @@ int vr_apply_prepare(vr_context *c) {
     c->sourceDirty = false;
   }
 
-  // ---- ray stream: one batch of up to 2^27 rays; larger launches run several batches and
-  // overlap the generator of batch b+1 (second stream) with the tracer of batch b ----------
+  // ---- ray stream: one batch of up to 2^27 rays; larger launches run several batches ----------
   const uint64_t span = last - first;
   uint32_t cap = (uint32_t)std::min<uint64_t>(span, 1ull << 27);
   if (const char *e = std::getenv("VR_BATCH_RAYS"))
     cap = (uint32_t)std::min<uint64_t>(span, std::max<long long>(256, std::atoll(e)));
   cap = std::max<uint32_t>(cap, 1u);
   c->batchCap = cap;
-  // Overlapping the generator of batch b+1 (second stream) with the tracer of batch b was
-  // measured SLOWER on MI355X (both kernels contend for the same CUs and smaller batches
-  // sort less coherently): 16.7 ms vs 14.7 ms per 1e8 rays.  Kept behind VR_OVERLAP=1.
-  c->overlap = false;
-  if (const char *e = std::getenv("VR_OVERLAP"))
-    c->overlap = std::atoi(e) != 0 && span > cap;
+  // (Overlapping the generator of batch b+1 on a second stream with the tracer of batch b was measured slower in every
+  //  round — 13.4 against 11.3 ms per C2 step in round 3: both kernels want the same issue slots and smaller batches
+  //  sort less coherently — and is gone from the code.)
   // sort bins: far-plane cells holding ~40 rays each, VR_BIN_CAP slots (measured: 64 / 32 -> 128 / 40: generator
   // 5.0 -> 4.75 ms, C2 +2.5 %)
   {
@@ -1055,10 +1158,6 @@ int vr_apply_prepare(vr_context *c) {
     }
     VR_HIP(c, c->dSlotRec.ensure_grow(slotsWant * recFloats));
     VR_HIP(c, c->dBinCount.ensure_grow(binsWant));
-    if (c->overlap) {
-      VR_HIP(c, c->dSlotRec2.ensure_grow(slots * recFloats));
-      VR_HIP(c, c->dBinCount2.ensure_grow((size_t)nb + 1));
-    }
   }
 
   // launch geometry of the persistent kernels
@@ -1066,10 +1165,12 @@ int vr_apply_prepare(vr_context *c) {
     // absorbing particles: a (nearly) flat surface is served by packets alone; a structured one
     // ends most rounds in per-lane walks and wants the straggler carry-over (MODE 2)
     // general particles on a flat surface of disks: the general kernel with the packet query's crediting (MODE 3)
-    c->traceMode = !c->absorb ? ((c->keyShare >= 0.95f && c->geo.geo == 0 && c->kernelParticle < (int)P_EXT) ? 3 : 0)
+    // (the lean extended kernel P_EXT — data labels, per-material sticking, global data — has the packet query's
+    //  crediting too; P_EXT_FULL, the instantiation with the rare options, stays on MODE 0)
+    c->traceMode = !c->absorb ? ((c->keyShare >= 0.95f && c->geo.geo == 0 && c->kernelParticle <= (int)P_EXT) ? 3 : 0)
                               : (c->keyShare >= 0.95f ? 1 : 2);
     if (const char *e = std::getenv("VR_GENERAL_FLAT"))
-      if (!c->absorb && c->geo.geo == 0 && c->kernelParticle < (int)P_EXT)
+      if (!c->absorb && c->geo.geo == 0 && c->kernelParticle <= (int)P_EXT)
         c->traceMode = std::atoi(e) ? 3 : 0;
     if (const char *e = std::getenv("VR_ABSORB_CARRY"))
       if (c->absorb)
@@ -1077,8 +1178,6 @@ int vr_apply_prepare(vr_context *c) {
     if (smallScene)
       c->traceMode = 4;
     int blocks = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->kernelParticle, c->traceMode, p.smallBytes));
-    if (c->overlap && blocks > 4)
-      blocks -= 2; // leave wave slots for the concurrently running generator / sorter
     if (const char *e = std::getenv("VR_TRACE_BLOCKS"))
       blocks = std::max(1, std::atoi(e));
     c->grid = (unsigned)c->numCUs * (unsigned)blocks;
@@ -1140,13 +1239,18 @@ int vr_apply_prepare(vr_context *c) {
   p.nbIds = c->dNbIds.p;
   p.primSticking = dStick;
   p.wallTable = c->dWalls.p;
-  p.fluxAcc = c->dFluxAcc.p;
+  p.planeStride = c->accStride * c->accReplicas;
+  p.fluxAcc = c->dFluxAcc.p + (size_t)c->dataBase * p.planeStride; // (this particle's planes)
   p.accStride = c->accStride;
   p.numData = c->numData;
-  p.planeStride = c->accStride * c->accReplicas;
   p.particleKind = c->particleKind;
-  p.coneAngle = c->coneAngle;
   p.meanFreePath = c->meanFreePath;
+  std::memcpy(p.particleParams, c->particleParams, sizeof(p.particleParams));
+  p.globalVec = (c->globalStride && !c->globalVecs.empty()) ? c->dGlobalVec.p : nullptr;
+  p.globalScalars = c->globalScalars.empty() ? nullptr : c->dGlobalScalars.p;
+  p.numGlobalVec = p.globalVec ? (uint32_t)c->globalVecs.size() : 0u;
+  p.globalStride = c->globalStride;
+  p.numGlobalScalars = (uint32_t)c->globalScalars.size();
   p.useWdist = c->useWdist ? 1 : 0;
   p.gridPoints = c->gridPoints.empty() ? nullptr : c->dGrid.p;
   p.gridCount = (uint32_t)(c->gridPoints.size() / 3);
@@ -1156,8 +1260,9 @@ int vr_apply_prepare(vr_context *c) {
   p.hostDraws = c->hostDraws.empty() ? nullptr : c->dHostDraws.p;
   p.hostWeights = (c->hostOrg.empty() || c->hostWeights.empty()) ? nullptr : c->dHostWeights.p;
   p.accMask = c->accReplicas - 1u;
-  p.counters = c->dCounters.p;
-  VR_HIP(c, c->dWorkQ.ensure(2 * VR_QUEUES * VR_QUEUE_STRIDE));
+  VR_HIP(c, c->dCounters.ensure(80 * std::max<size_t>(1, c->specs.size())));
+  p.counters = c->dCounters.p + 80 * (size_t)c->counterSlot;
+  VR_HIP(c, c->dWorkQ.ensure(VR_QUEUES * VR_QUEUE_STRIDE));
   p.workCounter = c->dWorkQ.p;
   p.numQueues = VR_QUEUES;
   p.rngScratch = c->dScratch.p;
@@ -1247,13 +1352,32 @@ static void size_bins(int D, uint64_t count, uint32_t perBin, TraceParams &p, ui
   }
 }
 
-// one batch of the ray stream: generate straight into the sort bins (stream2 when
-// overlapping), then trace
-static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batchNo) {
-  TraceParams p = c->params;
+// what one trace launch of a batch needs beyond the prepared parameters
+struct LaunchDesc {
+  const TraceParams *params;
+  unsigned grid;
+  int traceMode, kernelParticle;
+  bool absorb;
+};
+
+static hipEvent_t &event_at(std::vector<hipEvent_t> &v, size_t i, vr_context *c, int &rc) {
+  while (v.size() <= i) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {
+      rc = fail(c, VR_E_HIP, "hipEventCreate failed");
+      static hipEvent_t none = nullptr;
+      return none;
+    }
+    v.push_back(e);
+  }
+  return v[i];
+}
+
+// the batch's own fields of a particle's launch parameters: sort bins, spans per queue grab, queues
+static TraceParams batch_params(vr_context *c, const LaunchDesc &L, uint64_t first, uint32_t count) {
+  TraceParams p = *L.params;
   p.batchFirst = first;
   p.batchCount = count;
-  p.chunk = 32; // sort bins one wave pulls per queue access (~1024 rays)
   uint32_t nbBatch = c->numBins;
   size_bins(c->geo.D, count, c->raysPerBin, p, nbBatch); // (<= the grid the buffers were sized for)
   nbBatch = std::min(nbBatch, c->numBins);
@@ -1261,68 +1385,55 @@ static int run_batch(vr_context *c, uint64_t first, uint32_t count, size_t batch
   {
     // bins per queue grab: ~1024 rays for big batches, but never so many that a small
     // batch (a short last one, a small launch) is handed to a few waves only
-    const uint64_t waves = std::min<uint64_t>(c->grid, ((uint64_t)count + 255) / 256) * (VR_BLOCK / 64);
+    const uint64_t waves = std::min<uint64_t>(L.grid, ((uint64_t)count + 255) / 256) * (VR_BLOCK / 64);
     // (a grab of the queue costs two dependent trips to memory: the packet kernels want long spans; the
     //  general kernel's rounds are long and its bounce chains uneven: shorter spans balance its tail)
-    uint64_t spanBins = c->traceMode == 0 ? 16 : 32;
+    uint64_t spanBins = L.traceMode == 0 ? 16 : 32;
     if (const char *e = std::getenv("VR_SPAN_BINS"))
       spanBins = (uint64_t)std::min(64, std::max(1, std::atoi(e)));
     p.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spanBins, nbBatch / std::max<uint64_t>(waves * 2, 1)));
   }
-  const bool keepRng = !c->absorb; // records carry the RNG cursors
-  const unsigned slot = c->overlap ? (unsigned)(batchNo & 1) : 0u;
-  if (slot) {
-    p.slotRec = c->dSlotRec2.p;
-    p.binCount = c->dBinCount2.p;
-  }
-  p.workCounter = c->dWorkQ.p + (size_t)slot * VR_QUEUES * VR_QUEUE_STRIDE;
+  p.workCounter = c->dWorkQ.p;
   // One queue per XCD pays where neighbouring rounds share primitive records that do not fit an XCD's 4 MiB L2 and the
   // work per bin is even: flat scenes of more than ~10^5 primitives (measured, VR_QUEUES=1 / 8 on one box: C2 sticking
-  // 0.1 15.62 -> 15.16 ms, C2 1.0 6.67 -> 6.62, plane 100^2 +-0).  A structured scene is L2 resident anyway and its
-  // bins differ in cost — an eighth of the trench is not an eighth of the work: trench3D +3 %, C5 +6 %: one queue.
-  const bool flat = c->traceMode == 1 || c->traceMode == 3;
+  // 0.1 15.62 -> 15.16 ms, C2 1.0 6.67 -> 6.62, plane 100^2 +-0; L2 hit rate of the C2 launch 74 -> 84 %, fabric reads
+  // 9.0 -> 5.2 GB).  A structured scene is L2 resident anyway and its bins differ in cost — an eighth of the trench is
+  // not an eighth of the work: trench3D +3 %, C5 +6 %: one queue.
+  const bool flat = L.traceMode == 1 || L.traceMode == 3;
   p.numQueues = (flat && c->geo.numPrims > (1u << 17) && nbBatch >= 64u * VR_QUEUES * p.chunk) ? VR_QUEUES : 1u;
   if (const char *e = std::getenv("VR_QUEUES"))
     p.numQueues = std::atoi(e) >= (int)VR_QUEUES ? VR_QUEUES : 1u;
-  hipStream_t sg = c->overlap ? c->stream2 : c->stream;
-  while (c->evK.size() < 2 * (batchNo + 1)) {
-    hipEvent_t e;
-    VR_HIP(c, hipEventCreate(&e));
-    c->evK.push_back(e);
+  return p;
+}
+
+// One batch of the ray stream: ONE generator pass straight into the sort bins, then the trace kernel of every
+// particle of `group` over the same records (particles of a group share source distribution and record format).
+static int run_batch(vr_context *c, const std::vector<LaunchDesc> &group, uint64_t first, uint32_t count, size_t &genNo,
+                     size_t &traceNo) {
+  int rc = VR_OK;
+  const bool keepRng = !group[0].absorb; // records carry the RNG cursors
+  const TraceParams pg = batch_params(c, group[0], first, count);
+  VR_HIP(c, hipMemsetAsync(pg.binCount, 0, ((size_t)pg.numBins + 1) * 4, c->stream));
+  hipEvent_t g0 = event_at(c->evG, 2 * genNo, c, rc), g1 = event_at(c->evG, 2 * genNo + 1, c, rc);
+  if (rc != VR_OK)
+    return rc;
+  VR_HIP(c, hipEventRecord(g0, c->stream));
+  VR_HIP(c, launch_gen(pg, c->geo.D, keepRng, (unsigned)c->numCUs * 8u, c->stream));
+  VR_HIP(c, hipEventRecord(g1, c->stream));
+  ++genNo;
+  for (const LaunchDesc &L : group) {
+    const TraceParams p = &L == &group[0] ? pg : batch_params(c, L, first, count);
+    VR_HIP(c, hipMemsetAsync(p.workCounter, 0, VR_QUEUES * VR_QUEUE_STRIDE * 8, c->stream));
+    hipEvent_t k0 = event_at(c->evK, 2 * traceNo, c, rc), k1 = event_at(c->evK, 2 * traceNo + 1, c, rc);
+    if (rc != VR_OK)
+      return rc;
+    VR_HIP(c, hipEventRecord(k0, c->stream));
+    // a small batch does not need the whole persistent grid: one wave per 64 rays is plenty
+    const unsigned gridBatch = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(L.grid, ((uint64_t)count + 255) / 256));
+    VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, L.kernelParticle, L.traceMode, gridBatch, c->stream));
+    VR_HIP(c, hipEventRecord(k1, c->stream));
+    ++traceNo;
   }
-  while (c->evSort.size() <= batchNo) {
-    hipEvent_t e, f;
-    VR_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    VR_HIP(c, hipEventCreateWithFlags(&f, hipEventDisableTiming));
-    c->evSort.push_back(e);
-    c->evTraced.push_back(f);
-  }
-  // generator (writes the binned stream of this slot: free once batch b-2 is traced)
-  if (c->overlap && batchNo >= 2)
-    VR_HIP(c, hipStreamWaitEvent(sg, c->evTraced[batchNo - 2], 0));
-  VR_HIP(c, hipMemsetAsync(p.binCount, 0, ((size_t)p.numBins + 1) * 4, sg));
-  while (c->evG.size() < 2 * (batchNo + 1)) {
-    hipEvent_t e;
-    VR_HIP(c, hipEventCreate(&e));
-    c->evG.push_back(e);
-  }
-  VR_HIP(c, hipEventRecord(c->evG[2 * batchNo], sg));
-  VR_HIP(c, launch_gen(p, c->geo.D, keepRng, (unsigned)c->numCUs * 8u, sg));
-  VR_HIP(c, hipEventRecord(c->evG[2 * batchNo + 1], sg));
-  // tracer
-  if (c->overlap) {
-    VR_HIP(c, hipEventRecord(c->evSort[batchNo], sg));
-    VR_HIP(c, hipStreamWaitEvent(c->stream, c->evSort[batchNo], 0));
-  }
-  VR_HIP(c, hipMemsetAsync(p.workCounter, 0, VR_QUEUES * VR_QUEUE_STRIDE * 8, c->stream));
-  VR_HIP(c, hipEventRecord(c->evK[2 * batchNo], c->stream));
-  // a small batch does not need the whole persistent grid: one wave per 64 rays is plenty
-  const unsigned gridBatch =
-      (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(c->grid, ((uint64_t)count + 255) / 256));
-  VR_HIP(c, launch_trace(p, c->geo.D, c->geo.geo, c->kernelParticle, c->traceMode, gridBatch, c->stream));
-  VR_HIP(c, hipEventRecord(c->evK[2 * batchNo + 1], c->stream));
-  if (c->overlap)
-    VR_HIP(c, hipEventRecord(c->evTraced[batchNo], c->stream));
   return VR_OK;
 }
 
@@ -1333,26 +1444,55 @@ int vr_apply_launch(vr_context *c) {
     return fail(c, VR_E_STATE, "vr_apply_launch: call vr_apply_prepare first");
   VR_HIP(c, hipSetDevice(c->device));
   const uint32_t N = c->geo.numPrims;
-  VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)c->accStride * c->accReplicas * c->numData * 8, c->stream));
-  VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 80 * 8, c->stream));
+  const size_t nPart = std::max<size_t>(1, c->specs.size());
+  VR_HIP(c, hipMemsetAsync(c->dFluxAcc.p, 0, (size_t)c->accStride * c->accReplicas * c->totalData * 8, c->stream));
+  VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 80 * nPart * 8, c->stream));
   VR_HIP(c, hipEventRecord(c->ev0, c->stream));
-  if (c->overlap)
-    VR_HIP(c, hipStreamWaitEvent(c->stream2, c->ev0, 0));
-  c->numBatches = 0;
-  uint64_t f = c->rayFirstLaunch;
-  for (; f < c->rayEndLaunch; f += c->batchCap) {
-    const uint32_t cnt = (uint32_t)std::min<uint64_t>(c->batchCap, c->rayEndLaunch - f);
-    int r = run_batch(c, f, cnt, c->numBatches);
-    if (r != VR_OK)
-      return r;
-    ++c->numBatches;
+  // groups of particles that can share a generator pass: the same source distribution (cosine power: the rays of
+  // index idx are then identical, gpu/raygTrace.hpp launches every particle with the apply's one seed) and the
+  // same record format (with / without the RNG cursors)
+  std::vector<std::vector<LaunchDesc>> groups;
+  if (nPart == 1) {
+    groups.push_back({LaunchDesc{&c->params, c->grid, c->traceMode, c->kernelParticle, c->absorb}});
+  } else {
+    for (const ParticleLaunch &L : c->launches) {
+      const LaunchDesc d{&L.params, L.grid, L.traceMode, L.kernelParticle, L.absorb};
+      bool placed = false;
+      for (auto &g : groups)
+        if (g[0].absorb == d.absorb && g[0].params->ee == d.params->ee && g[0].params->eeGrid == d.params->eeGrid) {
+          g.push_back(d);
+          placed = true;
+          break;
+        }
+      if (!placed)
+        groups.push_back({d});
+    }
   }
+  c->numGenLaunches = c->numTraceLaunches = 0;
+  for (const auto &g : groups)
+    for (uint64_t f = c->rayFirstLaunch; f < c->rayEndLaunch; f += c->batchCap) {
+      const uint32_t cnt = (uint32_t)std::min<uint64_t>(c->batchCap, c->rayEndLaunch - f);
+      int r = run_batch(c, g, f, cnt, c->numGenLaunches, c->numTraceLaunches);
+      if (r != VR_OK)
+        return r;
+    }
   VR_HIP(c, hipEventRecord(c->ev1, c->stream));
-  for (uint32_t l = 0; l < c->numData; ++l)
+  for (uint32_t l = 0; l < c->totalData; ++l)
     VR_HIP(c, launch_gather_flux(c->dFluxAcc.p + (size_t)l * c->accStride * c->accReplicas, c->accStride, c->accReplicas,
                                  c->dLeafOfOrig.p, N, c->fluxOut() + (size_t)l * N, c->stream));
   c->launched = true;
   return VR_OK;
+}
+
+static void info_from_counters(vr_trace_info &i, const unsigned long long *cnt) {
+  i.totalRaysTraced = cnt[C_TRACES];
+  i.nonGeometryHits = cnt[C_NONGEO];
+  i.geometryHits = cnt[C_GEO];
+  i.particleHits = cnt[C_PARTICLE];
+  i.boundaryHits = cnt[C_BOUNDARY];
+  i.reflections = cnt[C_REFLECTIONS];
+  i.raysTerminated = cnt[C_TERMINATED];
+  i.rngFullStates = cnt[C_TIER2];
 }
 
 int vr_apply_finish(vr_context *c) {
@@ -1362,8 +1502,10 @@ int vr_apply_finish(vr_context *c) {
     return fail(c, VR_E_STATE, "vr_apply_finish: nothing launched");
   VR_HIP(c, hipSetDevice(c->device));
   VR_HIP(c, hipStreamSynchronize(c->stream));
-  unsigned long long cnt[64]; // [0..7] TraceInfo counters, [60] the walk's stack-overflow flag
-  VR_HIP(c, hipMemcpy(cnt, c->dCounters.p, sizeof(cnt), hipMemcpyDeviceToHost));
+  const size_t nPart = std::max<size_t>(1, c->specs.size());
+  std::vector<unsigned long long> all(80 * nPart); // per particle: [0..7] TraceInfo counters, [60] the walk's stack-overflow flag
+  VR_HIP(c, hipMemcpy(all.data(), c->dCounters.p, all.size() * 8, hipMemcpyDeviceToHost));
+  const unsigned long long *cnt = all.data();
 #ifdef VR_DIAG
   { // lane-occupancy diagnostics of a -DVR_DIAG build (see vr_trace.hip)
     unsigned long long dg[32];
@@ -1388,10 +1530,10 @@ int vr_apply_finish(vr_context *c) {
         std::fprintf(stderr, "phase %-24s %5.1f %% of wave time\n", pn[k], 100.0 * (double)ph[k] / tot);
   }
 #endif
-  {
+  for (size_t q = 0; q < nPart; ++q) {
     // the walk's stack ran out (a tree deeper than SD + VR_STACK_GLOBAL levels of deferred children): the
     // result would be wrong, so the apply fails
-    if (cnt[60]) {
+    if (all[80 * q + 60]) {
       c->launched = false;
       c->prepared = false;
       return fail(c, VR_E_STATE, "BVH traversal stack overflow (degenerate tree), or a rank of a sharded apply failed: result discarded");
@@ -1418,24 +1560,44 @@ int vr_apply_finish(vr_context *c) {
   VR_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
   vr_trace_info &i = c->info;
   i.numRays = c->numRaysLast;
-  i.totalRaysTraced = cnt[C_TRACES];
-  i.nonGeometryHits = cnt[C_NONGEO];
-  i.geometryHits = cnt[C_GEO];
-  i.particleHits = cnt[C_PARTICLE];
-  i.boundaryHits = cnt[C_BOUNDARY];
-  i.reflections = cnt[C_REFLECTIONS];
-  i.raysTerminated = cnt[C_TERMINATED];
-  i.rngFullStates = cnt[C_TIER2];
+  if (nPart == 1) {
+    info_from_counters(i, cnt);
+  } else {
+    // per particle, and their sums in the context's TraceInfo
+    vr_trace_info sum{};
+    for (size_t q = 0; q < nPart; ++q) {
+      vr_trace_info &pi = c->launches[q].info;
+      pi = vr_trace_info{};
+      pi.numRays = c->numRaysLast;
+      info_from_counters(pi, all.data() + 80 * q);
+      sum.totalRaysTraced += pi.totalRaysTraced;
+      sum.nonGeometryHits += pi.nonGeometryHits;
+      sum.geometryHits += pi.geometryHits;
+      sum.particleHits += pi.particleHits;
+      sum.boundaryHits += pi.boundaryHits;
+      sum.reflections += pi.reflections;
+      sum.raysTerminated += pi.raysTerminated;
+      sum.rngFullStates += pi.rngFullStates;
+    }
+    const uint64_t nr = i.numRays;
+    const int32_t w = i.warning, e = i.error;
+    i = sum;
+    i.numRays = nr;
+    i.warning = w;
+    i.error = e;
+  }
   i.timeTrace = ms * 1e-3;
   double kms = 0.0;
-  for (size_t b = 0; b < c->numBatches; ++b) {
+  for (size_t b = 0; b < c->numTraceLaunches; ++b) {
     float m = 0.f;
     VR_HIP(c, hipEventElapsedTime(&m, c->evK[2 * b], c->evK[2 * b + 1]));
     kms += m;
+    if (nPart > 1) // (batches of a group follow each other: launch b belongs to particle ... of its group; the
+      ;            //  per-particle kernel time is not broken out)
   }
   i.timeTraceKernel = kms * 1e-3;
   double gms = 0.0;
-  for (size_t b = 0; b < c->numBatches; ++b) {
+  for (size_t b = 0; b < c->numGenLaunches; ++b) {
     float m = 0.f;
     VR_HIP(c, hipEventElapsedTime(&m, c->evG[2 * b], c->evG[2 * b + 1]));
     gms += m;
@@ -1445,10 +1607,85 @@ int vr_apply_finish(vr_context *c) {
   i.time = i.timeBuild + i.timeTrace;
   i.bvhRefits = (uint32_t)c->bvhRefits;
   i.bvhBuilds = c->bvhBuilds;
+  for (auto &L : c->launches) {
+    L.info.timeTrace = i.timeTrace;
+    L.info.time = i.time;
+    L.info.timeBuild = i.timeBuild;
+  }
   ++c->runNumber; // rayTraceDisk.hpp:54
+  c->haveSharedSeed = c->keepSharedSeed && c->haveSharedSeed;
   c->launched = false;
   c->prepared = false;
   c->haveResult = true;
+  return VR_OK;
+}
+
+// Trace::apply() set-up.  One particle: prepare_one.  Several (vr_set_particles): every particle is prepared in
+// turn — its kernel variant, launch geometry, per-material sticking, accumulator planes and counter block — with
+// ONE seed for the whole apply (gpu/raygTrace.hpp:163-248).
+int vr_apply_prepare(vr_context *c) {
+  if (!c)
+    return VR_E_INVALID;
+  if (c->specs.size() <= 1) {
+    c->dataBase = 0;
+    c->counterSlot = 0;
+    return prepare_one(c);
+  }
+  if (c->useRandomSeed && !c->haveSharedSeed) { // one draw for all particles of this apply
+    std::random_device rd;
+    c->sharedSeed = (uint32_t)rd();
+    c->haveSharedSeed = true;
+    c->keepSharedSeed = false;
+  }
+  for (auto &L : c->launches)
+    if (L.primSticking) {
+      (void)hipFree(L.primSticking);
+      L.primSticking = nullptr;
+    }
+  c->launches.assign(c->specs.size(), ParticleLaunch{});
+  uint32_t base = 0;
+  for (size_t q = 0; q < c->specs.size(); ++q) {
+    activate_particle(c, c->specs[q]);
+    c->dataBase = base;
+    c->counterSlot = (uint32_t)q;
+    const int r = prepare_one(c);
+    if (r != VR_OK) {
+      activate_particle(c, c->specs[0]);
+      return r;
+    }
+    ParticleLaunch &L = c->launches[q];
+    L.params = c->params;
+    L.grid = c->grid;
+    L.traceMode = c->traceMode;
+    L.kernelParticle = c->kernelParticle;
+    L.absorb = c->absorb;
+    L.numData = c->numData;
+    L.dataBase = base;
+    if (c->havePrimSticking) { // this particle's sticking map: the next prepare would overwrite the shared buffer
+      L.primSticking = c->dPrimSticking.p;
+      L.params.primSticking = L.primSticking;
+      c->dPrimSticking.p = nullptr;
+      c->dPrimSticking.cap = 0;
+      c->havePrimSticking = false;
+    }
+    base += c->numData;
+  }
+  // the shared buffers were (re-)sized by each prepare in turn and only ever grow — a later particle may have moved
+  // one (records with RNG cursors after records without, a larger grid's walk stacks): everybody gets the final addresses
+  for (size_t q = 0; q < c->launches.size(); ++q) {
+    TraceParams &lp = c->launches[q].params;
+    lp.slotRec = c->dSlotRec.p;
+    lp.binCount = c->dBinCount.p;
+    lp.walkStack = c->dWalkStack.p;
+    lp.rngScratch = c->dScratch.p;
+    lp.workCounter = c->dWorkQ.p;
+    lp.counters = c->dCounters.p + 80 * q;
+    lp.fluxAcc = c->dFluxAcc.p + (size_t)c->launches[q].dataBase * lp.planeStride;
+  }
+  activate_particle(c, c->specs[0]);
+  c->dataBase = 0;
+  c->counterSlot = 0;
+  c->prepared = true;
   return VR_OK;
 }
 
@@ -1476,7 +1713,7 @@ int vr_apply_sharded(vr_context *c, int rank, int world, vr_allreduce_fn reduce,
   const uint64_t first = total * (uint64_t)rank / (uint64_t)world;
   const uint64_t last = total * (uint64_t)(rank + 1) / (uint64_t)world;
   const uint32_t N = c->geo.numPrims;
-  VR_HIP(c, c->dCounters.ensure(80));
+  VR_HIP(c, c->dCounters.ensure(80 * std::max<size_t>(1, c->specs.size())));
   c->haveSharedSeed = false;
   if (world > 1 && c->useRandomSeed) {
     // setUseRandomSeeds(true): every rank would draw its own seed and the shards would belong to different
@@ -1493,6 +1730,7 @@ int vr_apply_sharded(vr_context *c, int rank, int world, vr_allreduce_fn reduce,
     VR_HIP(c, hipStreamSynchronize(c->stream));
     c->sharedSeed = (uint32_t)word;
     c->haveSharedSeed = true;
+    c->keepSharedSeed = true; // (cleared below, after the launch)
   }
   int r = VR_OK;
   if (last > first) {
@@ -1508,34 +1746,35 @@ int vr_apply_sharded(vr_context *c, int rank, int world, vr_allreduce_fn reduce,
     c->rayCount = 1;
     r = vr_apply_prepare(c);
     if (r == VR_OK) {
-      VR_HIP(c, hipMemsetAsync(c->fluxOut(), 0, (size_t)N * c->numData * 8, c->stream));
-      VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 80 * 8, c->stream));
+      VR_HIP(c, hipMemsetAsync(c->fluxOut(), 0, (size_t)N * c->totalData * 8, c->stream));
+      VR_HIP(c, hipMemsetAsync(c->dCounters.p, 0, 80 * 8 * std::max<size_t>(1, c->specs.size()), c->stream));
       VR_HIP(c, hipEventRecord(c->ev0, c->stream));
       VR_HIP(c, hipEventRecord(c->ev1, c->stream));
-      c->numBatches = 0;
+      c->numGenLaunches = c->numTraceLaunches = 0;
       c->launched = true;
     }
   }
   c->rayFirst = 0;
   c->rayCount = 0;
   c->haveSharedSeed = false;
+  c->keepSharedSeed = false;
   if (world > 1) {
     // A rank that failed above still enters the collectives when it can (zeros and a raised failure word) —
     // the others would hang in them otherwise.  The TraceInfo counters [0..7] AND the failure word [60] (the
     // walk's stack overflow, or this) travel together: every rank fails together, none returns VR_OK
     // holding sums that include a discarded share.
     const std::string firstErr = c->err;
-    const bool haveBuf = c->boundFlux ? c->boundFluxN == N * c->numData : c->dFluxOrig.cap >= (size_t)N * c->numData;
+    const bool haveBuf = c->boundFlux ? c->boundFluxN == N * c->totalData : c->dFluxOrig.cap >= (size_t)N * c->totalData;
     if (r != VR_OK) {
       if (!haveBuf)
         return r; // (failed before the accumulators existed: a configuration error, the same on every rank)
       const unsigned long long one = 1;
-      (void)hipMemsetAsync(c->fluxOut(), 0, (size_t)N * c->numData * 8, c->stream);
-      (void)hipMemsetAsync(c->dCounters.p, 0, 80 * 8, c->stream);
+      (void)hipMemsetAsync(c->fluxOut(), 0, (size_t)N * c->totalData * 8, c->stream);
+      (void)hipMemsetAsync(c->dCounters.p, 0, 80 * 8 * std::max<size_t>(1, c->specs.size()), c->stream);
       (void)hipMemcpyAsync(c->dCounters.p + 60, &one, 8, hipMemcpyHostToDevice, c->stream);
     }
-    if (reduce(user, c->fluxOut(), (size_t)N * c->numData, (void *)c->stream) != 0 ||
-        reduce(user, c->dCounters.p, 64, (void *)c->stream) != 0)
+    if (reduce(user, c->fluxOut(), (size_t)N * c->totalData, (void *)c->stream) != 0 ||
+        reduce(user, c->dCounters.p, 80 * std::max<size_t>(1, c->specs.size()), (void *)c->stream) != 0)
       return fail(c, VR_E_HIP, "vr_apply_sharded: the all-reduce callback failed");
     if (r != VR_OK) {
       (void)hipStreamSynchronize(c->stream);
@@ -1551,7 +1790,7 @@ int vr_apply_sharded(vr_context *c, int rank, int world, vr_allreduce_fn reduce,
 // ---- results --------------------------------------------------------------------
 uint32_t vr_num_primitives(const vr_context *c) { return c ? c->geo.numPrims : 0; }
 
-uint32_t vr_num_data(const vr_context *c) { return c ? c->numData : 0; }
+uint32_t vr_num_data(const vr_context *c) { return c ? c->totalData : 0; }
 
 static int get_flux_plane_f64(vr_context *c, uint32_t dataIdx, double *out, uint32_t n);
 
@@ -1577,7 +1816,7 @@ static int get_flux_plane_f64(vr_context *c, uint32_t dataIdx, double *out, uint
     return fail(c, VR_E_STATE, "vr_get_flux: no result (call vr_apply)");
   if (n != c->geo.numPrims)
     return fail(c, VR_E_INVALID, "vr_get_flux: size mismatch");
-  if (dataIdx >= c->numData)
+  if (dataIdx >= c->totalData)
     return fail(c, VR_E_INVALID, "vr_get_flux_data: the particle has no such data label");
   VR_HIP(c, hipSetDevice(c->device));
   std::vector<unsigned long long> acc(n);
@@ -1604,6 +1843,21 @@ int vr_get_trace_info(const vr_context *c, vr_trace_info *out) {
   if (!c || !out)
     return VR_E_INVALID;
   *out = c->info;
+  return VR_OK;
+}
+
+int vr_get_particle_trace_info(const vr_context *c, uint32_t q, vr_trace_info *out) {
+  if (!c || !out)
+    return VR_E_INVALID;
+  if (c->specs.size() <= 1) {
+    if (q != 0)
+      return VR_E_INVALID;
+    *out = c->info;
+    return VR_OK;
+  }
+  if (q >= c->launches.size())
+    return VR_E_INVALID;
+  *out = c->launches[q].info;
   return VR_OK;
 }
 
@@ -1636,14 +1890,14 @@ int vr_flux_accumulators(vr_context *c, void **devPtr, uint32_t *n) {
     return fail(c, VR_E_STATE, "vr_flux_accumulators: no result");
   *devPtr = c->fluxOut();
   if (n)
-    *n = c->geo.numPrims * c->numData;
+    *n = c->geo.numPrims * c->totalData;
   return VR_OK;
 }
 
 int vr_bind_flux_accumulators(vr_context *c, void *devPtr, uint32_t n) {
   if (!c)
     return VR_E_INVALID;
-  if (devPtr && n != c->geo.numPrims * c->numData)
+  if (devPtr && n != c->geo.numPrims * c->totalData)
     return fail(c, VR_E_INVALID, "vr_bind_flux_accumulators: size mismatch (numPrims x data labels; set geometry and particle first)");
   c->boundFlux = (unsigned long long *)devPtr;
   c->boundFluxN = devPtr ? n : 0;

@@ -1,22 +1,26 @@
 // vr_particles.hpp — the device-side particle registry.
 //
 // The reference's extension point is AbstractParticle (rayParticle.hpp:21-81): virtual
-// surfaceCollision / surfaceReflection / initNew called per hit on the host.  Its own GPU
-// path replaces the virtuals by a table of device callables per particle (COLLISION,
-// REFLECTION, INIT: gpu/raygCallableConfig.hpp:7-18, gpu/pipelines/Particle.cuh:15-39).
-// Here a particle model is a struct of __device__ functions; models are compiled into
-// trace_kernel — the two built-ins as their own instantiations (no run-time dispatch in the
-// hot kernels), everything else through the EXTENDED instantiation, which switches on
-// TraceParams::particleKind.  Adding a model = one struct here + one case in the switch of
-// `Particles::reflect` / `Particles::collide` + a VR_PARTICLE_* id in include/viennaray_amd.h
-// (and the matching host class in include/viennaray_amd/viennaray.hpp).
+// surfaceCollision / surfaceReflection / initNew called per hit on the host, each handed the primitive id, the
+// material id and `const TracingData *globalData`.  Its own GPU path replaces the virtuals by a table of device
+// callables per particle (COLLISION, REFLECTION, INIT: gpu/raygCallableConfig.hpp:7-18,
+// gpu/pipelines/Particle.cuh:15-39).  Here a particle MODEL is a struct of __device__ functions with one fixed
+// shape (below); models are compiled into trace_kernel — the two built-ins as their own instantiations (no
+// run-time dispatch in the hot kernels), everything else through the EXTENDED instantiations, which select the
+// model of TraceParams::particleKind from the type list `Registry`.
 //
-//   collide : what one surface hit adds to the particle's data labels (TracingData vectors);
-//             called for the closest disk and for every overlapping neighbour with that
-//             disk's own normal (rayTraceKernel.hpp:284-300); label l of primitive q is
-//             credit(l, q, value)
-//   reflect : (sticking is resolved by the caller: per-material map or the particle's value)
-//             the direction after the hit; consumes engine outputs exactly like the host code
+// Adding a model: write the struct, append it to `Registry` (its position is its kind id, VR_PARTICLE_* in
+// include/viennaray_amd.h), give the host class a deviceModel() (include/viennaray_amd/viennaray.hpp).  A model
+// reads its own parameters from ModelCtx::params (vr_particle::params, 8 floats) and the caller's global data
+// (vr_set_global_data) from ModelCtx::global — no change to the kernels or the C ABI.
+//
+//   sticking : the first member of surfaceReflection's result (rayParticle.hpp:44-50): the share of the weight
+//              that stays on primitive `primID`.  `base` is the particle's stickingProbability after the
+//              per-material map (gpu::Particle::materialSticking)
+//   reflect  : the second member: the direction after the hit; consumes engine outputs exactly like the host code
+//   collide  : surfaceCollision (rayParticle.hpp:60-68): what one hit adds to the particle's data labels; called
+//              for the closest disk and for every overlapping neighbour with that disk's own normal and id
+//              (rayTraceKernel.hpp:284-300); credit(label, value) adds to this primitive's entry of a label
 #pragma once
 #include "vr_device.hpp"
 
@@ -101,30 +105,156 @@ __device__ __forceinline__ V3 reflection_coned_cosine(const V3 &rayDir, const V3
   return dir;
 }
 
-struct Particles {
-  // number of data labels of a kind
-  __host__ __device__ static int numData(int kind) { return kind == P_DIFFUSE_COSINE ? 2 : 1; }
+// ---------------------------------------------------------------------------------------------------------
+// what a model sees of the launch: its own parameters and the caller's global data (Trace::setGlobalData,
+// rayTrace.hpp:137-145: a borrowed, read-only TracingData handed to every surfaceCollision / surfaceReflection)
+// ---------------------------------------------------------------------------------------------------------
+struct GlobalData {
+  const float *vec;        // [numVec][stride], indexed by the ORIGINAL primitive id (the primID of the host callbacks)
+  const float *scalars;    // [numScalars]
+  unsigned numVec, stride, numScalars;
+  // TracingData::getVectorData(v)[i]; a vector the caller did not provide reads as 0
+  __device__ __forceinline__ float vector(unsigned v, unsigned i) const {
+    return (v < numVec && i < stride) ? vec[(size_t)v * stride + i] : 0.f;
+  }
+  __device__ __forceinline__ float scalar(unsigned s) const { return s < numScalars ? scalars[s] : 0.f; }
+};
 
-  // surfaceReflection: new direction (the engine outputs it draws are part of the contract)
-  // CONED: the instantiation carries the coned-cosine model (P_EXT_FULL); the host never sends that kind to the other
-  template <int D, bool CONED>
-  __device__ __forceinline__ static V3 reflect(int kind, const TraceParams &p, const V3 &rayDir, const V3 &n, Rng &rng,
-                                               unsigned &t2) {
-    if (CONED && kind == P_CONED_COSINE)
-      return reflection_coned_cosine<D>(rayDir, n, rng, t2, p.coneAngle);
-    if (kind == P_SPECULAR)
-      return reflect_specular(rayDir, n);
-    return reflection_diffuse<D>(n, rng, t2); // P_DIFFUSE, P_DIFFUSE_COSINE
+struct ModelCtx {
+  const float *params; // vr_particle::params
+  GlobalData global;
+};
+
+__device__ __forceinline__ ModelCtx model_ctx(const TraceParams &p) {
+  ModelCtx m;
+  m.params = p.particleParams;
+  m.global.vec = p.globalVec;
+  m.global.scalars = p.globalScalars;
+  m.global.numVec = p.numGlobalVec;
+  m.global.stride = p.globalStride;
+  m.global.numScalars = p.numGlobalScalars;
+  return m;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the models
+// ---------------------------------------------------------------------------------------------------------
+// DiffuseParticle (rayParticle.hpp:126-163)
+struct ModelDiffuse {
+  static constexpr int kNumData = 1;
+  static constexpr bool kNeedsFull = false;
+  __device__ static float sticking(const ModelCtx &, unsigned, float base) { return base; }
+  template <int D>
+  __device__ static V3 reflect(const ModelCtx &, const V3 &, const V3 &n, Rng &rng, unsigned &t2) {
+    return reflection_diffuse<D>(n, rng, t2);
+  }
+  template <class Credit>
+  __device__ static void collide(const ModelCtx &, float w, const V3 &, const V3 &, unsigned, Credit &&credit) {
+    credit(0, w);
+  }
+};
+
+// SpecularParticle (rayParticle.hpp:165-204)
+struct ModelSpecular : ModelDiffuse {
+  template <int D>
+  __device__ static V3 reflect(const ModelCtx &, const V3 &rayDir, const V3 &n, Rng &, unsigned &) {
+    return reflect_specular(rayDir, n);
+  }
+};
+
+// surfaceReflection = ReflectionConedCosine(coneAngle) (rayReflection.hpp:52-120); params[0] = maxConeAngle
+struct ModelConedCosine : ModelDiffuse {
+  static constexpr bool kNeedsFull = true; // (double-precision trigonometry: the instantiation with the rare options)
+  template <int D>
+  __device__ static V3 reflect(const ModelCtx &m, const V3 &rayDir, const V3 &n, Rng &rng, unsigned &t2) {
+    return reflection_coned_cosine<D>(rayDir, n, rng, t2, m.params[0]);
+  }
+};
+
+// a DiffuseParticle with TWO data labels: label 0 += w, label 1 += w * max(0, -d.n)
+struct ModelDiffuseCosine : ModelDiffuse {
+  static constexpr int kNumData = 2;
+  template <class Credit>
+  __device__ static void collide(const ModelCtx &, float w, const V3 &rayDir, const V3 &n, unsigned, Credit &&credit) {
+    credit(0, w);
+    const float cosTheta = -vdot(rayDir, n);
+    credit(1, w * fmaxf(cosTheta, 0.f));
+  }
+};
+
+// The ViennaPS pattern the global data exists for: a diffuse particle whose sticking falls with the coverage of
+// the surface it meets, sticking = s0 * (1 - coverage[primID]), coverage = global vector params[0] (default 0).
+// Host form: surfaceReflection returns {s0 * (1 - globalData->getVectorData(v)[primID]), ReflectionDiffuse}.
+struct ModelCoverageSticking : ModelDiffuse {
+  __device__ static float sticking(const ModelCtx &m, unsigned primID, float base) {
+    return base * (1.f - m.global.vector((unsigned)m.params[0], primID));
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// registry: position = kind id (VR_PARTICLE_*)
+// ---------------------------------------------------------------------------------------------------------
+template <class... M> struct ModelList {
+  static constexpr int size = (int)sizeof...(M);
+};
+using Registry = ModelList<ModelDiffuse, ModelSpecular, ModelConedCosine, ModelDiffuseCosine, ModelCoverageSticking>;
+
+template <int I, class List> struct ModelAt;
+template <int I, class M0, class... M> struct ModelAt<I, ModelList<M0, M...>> : ModelAt<I - 1, ModelList<M...>> {};
+template <class M0, class... M> struct ModelAt<0, ModelList<M0, M...>> {
+  using type = M0;
+};
+
+struct Particles {
+  static constexpr int count = Registry::size;
+
+  // run f(Model{}) for the model of `kind`; FULL: the instantiation that carries the models with kNeedsFull
+  // (the host never sends such a kind to the lean one)
+  template <bool FULL, int I = 0, class F> __device__ __forceinline__ static void with(int kind, F &&f) {
+    if constexpr (I < Registry::size) {
+      using M = typename ModelAt<I, Registry>::type;
+      if constexpr (FULL || !M::kNeedsFull) {
+        if (kind == I) {
+          f(M{});
+          return;
+        }
+      }
+      with<FULL, I + 1>(kind, static_cast<F &&>(f));
+    }
   }
 
-  // surfaceCollision: `credit(label, value)` adds to this primitive's entry of a data label
-  template <class Credit>
-  __device__ __forceinline__ static void collide(int kind, float w, const V3 &rayDir, const V3 &n, Credit &&credit) {
-    credit(0, w);
-    if (kind == P_DIFFUSE_COSINE) {
-      const float cosTheta = -vdot(rayDir, n);
-      credit(1, w * fmaxf(cosTheta, 0.f));
+  template <int I = 0> __host__ __device__ static int numData(int kind) {
+    if constexpr (I < Registry::size) {
+      return kind == I ? ModelAt<I, Registry>::type::kNumData : numData<I + 1>(kind);
+    } else {
+      return 1;
     }
+  }
+  template <int I = 0> __host__ __device__ static bool needsFull(int kind) {
+    if constexpr (I < Registry::size) {
+      return kind == I ? ModelAt<I, Registry>::type::kNeedsFull : needsFull<I + 1>(kind);
+    } else {
+      return false;
+    }
+  }
+
+  template <bool FULL>
+  __device__ __forceinline__ static float sticking(int kind, const ModelCtx &m, unsigned primID, float base) {
+    float s = base;
+    with<FULL>(kind, [&](auto model) { s = decltype(model)::sticking(m, primID, base); });
+    return s;
+  }
+  template <int D, bool FULL>
+  __device__ __forceinline__ static V3 reflect(int kind, const ModelCtx &m, const V3 &rayDir, const V3 &n, Rng &rng,
+                                               unsigned &t2) {
+    V3 r = rayDir;
+    with<FULL>(kind, [&](auto model) { r = decltype(model)::template reflect<D>(m, rayDir, n, rng, t2); });
+    return r;
+  }
+  template <bool FULL, class Credit>
+  __device__ __forceinline__ static void collide(int kind, const ModelCtx &m, float w, const V3 &rayDir, const V3 &n,
+                                                 unsigned primID, Credit &&credit) {
+    with<FULL>(kind, [&](auto model) { decltype(model)::collide(m, w, rayDir, n, primID, credit); });
   }
 };
 

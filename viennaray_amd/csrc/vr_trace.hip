@@ -356,6 +356,17 @@ __device__ __forceinline__ void credit_aggregated(unsigned long long *acc, bool 
   }
 }
 
+// Every lane of the wave adds `wfx` (0: nothing) to the SAME accumulator `pos`: one integer wave sum (exact, order
+// independent) and one atomic.  Must be reached by the whole wave.
+__device__ __forceinline__ void credit_wave_sum(unsigned long long *acc, unsigned pos, u64 wfx) {
+  u64 s = wfx;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    s += (u64)__shfl_down((unsigned long long)s, off, 64);
+  if ((threadIdx.x & 63u) == 0u && s)
+    atomicAdd(&acc[pos], s);
+}
+
 __device__ __forceinline__ unsigned long long bcast64(unsigned long long v) {
   unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xFFFFFFFFull));
   unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -428,7 +439,7 @@ trace_kernel(const TraceParams p) {
   constexpr bool EXT_FULL = PARTICLE == P_EXT_FULL; // ... with the coned-cosine model, WDIST crediting and the mean free path
   // packet-query rounds credit disks wave-uniformly from the candidate list (pq_credit) instead of
   // walking the neighbour CSR per lane
-  constexpr bool PQ_CREDIT = GEO == 0 && !EXT && (MODE == 1 || MODE == 3);
+  constexpr bool PQ_CREDIT = GEO == 0 && !EXT_FULL && (MODE == 1 || MODE == 3);
   PqCands cands;
   cands.local = 0ull;
   cands.count = 0u;
@@ -767,6 +778,8 @@ trace_kernel(const TraceParams p) {
 
     bool creditLane = false;
     u64 creditW = 0;
+    float creditWf = 0.f; // (registry particles: the weight as the model's collide sees it ...
+    V3 creditDir = mk(0.f, 0.f, 0.f); //  ... and the INCOMING direction: the state machine replaces it by the reflected one)
     SUB_MARK(12); // (since the walls: the aggregation vote)
     if (fin) {
       DIAG(5);
@@ -828,6 +841,9 @@ trace_kernel(const TraceParams p) {
             if (PQ_CREDIT && pqCredit) {
               creditLane = true; // credited after the state machine, for the whole wave at once (pq_credit)
               creditW = wfx;
+              creditWf = rayWeight;
+              if (EXT)
+                creditDir = rayDirection;
             } else if (!EXT) {
               // surfaceCollision, rayParticle.hpp:148-156.  Without aggregation the credits of the neighbour
               // disks are first collected (three in registers; further ones, rare, go out at once) and then issued
@@ -884,10 +900,11 @@ trace_kernel(const TraceParams p) {
               // labels receive; with WDIST the weight is shared by inverse impact distance
               // (rayTraceKernel.hpp:258-296: w / d_i / sum(1/d) * numDisksHit, closest disk first)
               const int kind = p.particleKind;
+              const ModelCtx mctx = model_ctx(p);
               // (a coarse scene under sorted rays: a good share of the wave credits ONE disk — merged per distinct
               //  weight like the built-in particles' credits, or the 64 lanes queue up on one address in L2)
-              auto creditTo = [&](unsigned q, float w, const V3 &nq) {
-                Particles::collide(kind, w, rayDirection, nq, [&](int label, float v) {
+              auto creditTo = [&](unsigned q, float w, const V3 &nq, unsigned origId) {
+                Particles::collide<EXT_FULL>(kind, mctx, w, rayDirection, nq, origId, [&](int label, float v) {
                   unsigned long long *plane = fluxAcc + (size_t)label * (SMALL ? p.numPrims : p.planeStride);
                   if (aggregate && !SMALL) // (LDS accumulators take 64 adds on one address in their stride)
                     credit_aggregated(plane, true, q, weight_fx(v));
@@ -914,7 +931,7 @@ trace_kernel(const TraceParams p) {
                     }
                   }
                 }
-                creditTo(h.pos, (EXT_FULL && p.useWdist) ? rayWeight / dClosest / invSum * (float)numHit : rayWeight, geomNormal);
+                creditTo(h.pos, (EXT_FULL && p.useWdist) ? rayWeight / dClosest / invSum * (float)numHit : rayWeight, geomNormal, h.prim);
                 // (as in the built-in particles' loop: the next id is fetched while this neighbour is tested, and both
                 //  record words are requested together — one dependent access per neighbour instead of three)
                 unsigned qNext = nb < ne ? nbIds[nb] : 0u;
@@ -927,10 +944,11 @@ trace_kernel(const TraceParams p) {
                   const V3 nq = mk(n4.x, n4.y, n4.z);
                   float dist;
                   if (local_disc_hit_dist(org, dir, c4, nq, dist))
-                    creditTo(q, (EXT_FULL && p.useWdist) ? rayWeight / (dist + 1e-6f) / invSum * (float)numHit : rayWeight, nq);
+                    creditTo(q, (EXT_FULL && p.useWdist) ? rayWeight / (dist + 1e-6f) / invSum * (float)numHit : rayWeight, nq,
+                             __float_as_uint(n4.w));
                 }
               } else {
-                creditTo(h.pos, rayWeight, geomNormal);
+                creditTo(h.pos, rayWeight, geomNormal, h.prim);
               }
             }
             if (ABSORB) {
@@ -938,7 +956,9 @@ trace_kernel(const TraceParams p) {
               // the reference makes before that test (Q2) are not observable.
               active = false;
             } else {
-              const float sticking = p.primSticking ? primSticking[h.pos] : p.sticking;
+              float sticking = p.primSticking ? primSticking[h.pos] : p.sticking;
+              if (EXT) // (a registry model may make it depend on the primitive and the caller's global data)
+                sticking = Particles::sticking<EXT_FULL>(p.particleKind, model_ctx(p), h.prim, sticking);
               const float wAfter = rayWeight - rayWeight * sticking;
               if (wAfter <= 0.f) {
                 active = false; // as above: the pending draws die with the ray
@@ -951,7 +971,7 @@ trace_kernel(const TraceParams p) {
                 else if (PARTICLE == 1)
                   newDir = reflect_specular(rayDirection, geomNormal);
                 else
-                  newDir = Particles::reflect<D, EXT_FULL>(p.particleKind, p, rayDirection, geomNormal, rng, cnt[K_TIER2 * VR_BLOCK]);
+                  newDir = Particles::reflect<D, EXT_FULL>(p.particleKind, model_ctx(p), rayDirection, geomNormal, rng, cnt[K_TIER2 * VR_BLOCK]);
                 rayWeight = wAfter;
                 if (++numReflections > p.maxReflections) { // :320-324
                   VR_COUNT(K_TERM, 1);
@@ -1016,7 +1036,29 @@ trace_kernel(const TraceParams p) {
           bool near = fabsf(dx) <= dist && fabsf(dy) <= dist && (p.geoD == 2 || fabsf(dz) <= dist);
           near = near && ((dx * dx + dy * dy) + dz * dz) <= dist2;
           const bool sel = creditLane && (h.pos == q || (near && ((cands.local >> c) & 1ull)));
-          if (ABSORB) {
+          if (EXT) {
+            // registry particles: the model's collide runs per lane with candidate q's own normal and id (its credits
+            // are only RECORDED per lane — a model may credit under any condition of its own — and then summed over the
+            // wave label by label: every selected lane adds to ONE address, q's entry of the label's plane)
+            if (ballot64(sel)) {
+              const float4 n4 = prims[2 * (size_t)q + 1];
+              float val[VR_MAX_LABELS];
+#pragma unroll
+              for (int l = 0; l < VR_MAX_LABELS; ++l)
+                val[l] = 0.f;
+              if (sel)
+                Particles::collide<EXT_FULL>(p.particleKind, model_ctx(p), creditWf, creditDir, mk(n4.x, n4.y, n4.z),
+                                             __float_as_uint(n4.w), [&](int label, float v) {
+#pragma unroll
+                                               for (int l = 0; l < VR_MAX_LABELS; ++l)
+                                                 val[l] = l == label ? val[l] + v : val[l];
+                                             });
+#pragma unroll
+              for (int l = 0; l < VR_MAX_LABELS; ++l)
+                if ((unsigned)l < p.numData)
+                  credit_wave_sum(fluxAcc + (size_t)l * p.planeStride, q, sel ? weight_fx(val[l]) : 0ull);
+            }
+          } else if (ABSORB) {
             const unsigned long long m = ballot64(sel);
             if (m && lane == (unsigned)(__ffsll((long long)m) - 1))
               atomicAdd(&fluxAcc[q], (u64)__popcll(m) * 1099511627776ull); // unit weights: count x 2^40
@@ -1109,8 +1151,8 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 1>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 2)
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 2>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
-  else if (mode == 3 && GEO == 0 && PARTICLE < P_EXT)
-    hipLaunchKernelGGL((trace_kernel<D, 0, PARTICLE >= P_EXT ? 0 : PARTICLE, 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  else if (mode == 3 && GEO == 0 && PARTICLE <= P_EXT)
+    hipLaunchKernelGGL((trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 4)
     hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 4>), dim3(grid), dim3(VR_BLOCK), p.smallBytes, s, p);
   else
@@ -1151,8 +1193,8 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode, unsigned smal
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 1>, VR_BLOCK, 0);
   else if (mode == 2)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 2>, VR_BLOCK, 0);
-  else if (mode == 3 && GEO == 0 && PARTICLE < P_EXT)
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, PARTICLE >= P_EXT ? 0 : PARTICLE, 3>, VR_BLOCK, 0);
+  else if (mode == 3 && GEO == 0 && PARTICLE <= P_EXT)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 3>, VR_BLOCK, 0);
   else if (mode == 4)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 4>, VR_BLOCK, smallBytes);
   else

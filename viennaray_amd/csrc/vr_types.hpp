@@ -36,6 +36,7 @@ struct Tri {       // boundary wall triangle, Embree's precomputed form
 constexpr unsigned VR_BIN_CAP = 128; // record slots per sort bin (4 KB of 32-byte records: the generator's scattered stores
                                     // and the bin cursors do better with bins a page apart than with 64 slots)
 constexpr int VR_BLOCK = 256;
+constexpr int VR_MAX_LABELS = 4;         // data labels one particle model may have
 constexpr unsigned VR_QUEUES = 8;        // work queues of the trace kernel: one per XCD
 constexpr unsigned VR_QUEUE_STRIDE = 16; // u64 words between two queue cursors
 // stack of the ordered per-lane walk: the first entries of a lane live in LDS ([entry][lane], 12 in
@@ -83,7 +84,12 @@ struct TraceParams {
   uint32_t numData, planeStride; // data label l (TracingData vector l) lives at fluxAcc + l * planeStride
   // particle plug-ins (vr_particles.hpp): run-time kind of the extended kernel instantiation
   int32_t particleKind;
-  float coneAngle, meanFreePath;
+  float meanFreePath;
+  float particleParams[8];       // vr_particle::params: the model's own parameters (ModelCtx::params)
+  // Trace::setGlobalData (rayTrace.hpp:137-145): read-only vectors indexed by the ORIGINAL primitive id, and scalars
+  const float *globalVec;        // [numGlobalVec][globalStride] or nullptr
+  const float *globalScalars;    // [numGlobalScalars] or nullptr
+  uint32_t numGlobalVec, globalStride, numGlobalScalars;
   int32_t useWdist;              // VIENNARAY_USE_WDIST crediting (rayTraceKernel.hpp:258-296)
   // sources other than SourceRandom: SourceGrid origins (raySourceGrid.hpp), or rays a host-side
   // Source callback produced (origin, direction, engine outputs it consumed)
@@ -166,7 +172,8 @@ struct SetupParams {
 };
 
 // particle kinds of the device registry (include/viennaray_amd.h: VR_PARTICLE_*)
-enum { P_DIFFUSE = 0, P_SPECULAR = 1, P_CONED_COSINE = 2, P_DIFFUSE_COSINE = 3, P_EXT = 2 /* template id of the extended kernel */,
+enum { P_DIFFUSE = 0, P_SPECULAR = 1, P_CONED_COSINE = 2, P_DIFFUSE_COSINE = 3, P_COVERAGE_STICKING = 4,
+       P_EXT = 2 /* template id of the extended kernel */,
        P_EXT_FULL = 3 /* ... with the coned-cosine model, WDIST crediting and mean-free-path scattering compiled in
                          (rare options that cost every particle of the instantiation registers: 157 spilled VGPRs
                          with them, 27 without) */ };

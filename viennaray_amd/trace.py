@@ -121,6 +121,26 @@ class DiffuseCosineParticle:
         return list(self.dataLabels)
 
 
+class CoverageStickingParticle:
+    """Plug-in particle reading Trace.setGlobalData: a DiffuseParticle whose sticking falls with the coverage of the
+    primitive it meets, sticking * (1 - globalData.getVectorData(coverageVector)[primID]) — the host form returns
+    that as the first member of surfaceReflection (rayParticle.hpp:44-50)."""
+    kind = 4
+
+    def __init__(self, stickingProbability, dataLabel, coverageVector=0, materialSticking=None):
+        self.stickingProbability = float(stickingProbability)
+        self.dataLabel = dataLabel
+        self.coverageVector = int(coverageVector)
+        self.materialSticking = dict(materialSticking or {})
+        self.params = [float(self.coverageVector)]
+
+    def getSourceDistributionPower(self):
+        return 1.0
+
+    def getLocalDataLabels(self):
+        return [self.dataLabel]
+
+
 class SourceGrid:
     """raySourceGrid.hpp: explicit ray origins (createSourceGrid, rayUtil.hpp:564-611); the direction
     comes from the particle's cosine power."""
@@ -240,25 +260,64 @@ class Trace:
             raise VrError(self._L.vr_last_error(self._h).decode())
 
     # --- setters (rayTrace.hpp:41-121) --------------------------------------
-    def setParticleType(self, particle):
-        self._particle = particle
+    def _pod(self, particle, keep):
         pod = ParticlePOD()
         pod.kind = particle.kind
         pod.sticking = particle.stickingProbability
         pod.sourcePower = particle.getSourceDistributionPower()
         pod.coneAngle = getattr(particle, "coneAngle", 0.0)
         pod.meanFreePath = getattr(particle, "meanFreePath", -1.0)
+        for k, v in enumerate(getattr(particle, "params", [])[:8]):
+            pod.params[k] = v
         ms = particle.materialSticking
-        keep = None
         if ms:
             ids = (C.c_int32 * len(ms))(*ms.keys())
             vals = (C.c_float * len(ms))(*ms.values())
             pod.numMaterialSticking = len(ms)
             pod.materialIds = ids
             pod.materialSticking = vals
-            keep = (ids, vals)
+            keep.append((ids, vals))
+        return pod
+
+    def setParticleType(self, particle):
+        self._particle = particle
+        self._particles = [particle]
+        keep = []
+        pod = self._pod(particle, keep)
         self._check(self._L.vr_set_particle(self._h, C.byref(pod)))
         del keep
+
+    def setParticleTypes(self, particles):
+        """Several particles traced in ONE apply() (the reference's gpu::Trace keeps a particle list,
+        gpu/raygTrace.hpp:163-248): every particle sees the same seed, particles with the same source
+        distribution share one generator pass; getLocalData() holds particle 0's labels, then particle 1's, ..."""
+        particles = list(particles)
+        keep = []
+        arr = (ParticlePOD * len(particles))(*[self._pod(q, keep) for q in particles])
+        self._check(self._L.vr_set_particles(self._h, arr, len(particles)))
+        self._particle = particles[0]
+        self._particles = particles
+        del keep
+
+    def setGlobalData(self, data):
+        """rayTrace.hpp:141: a TracingData (or a list of per-primitive arrays) the device particle models may read"""
+        vecs = data._vectors if isinstance(data, TracingData) else list(data)
+        self._check(self._L.vr_set_global_data(self._h, 0, None, 0))
+        for k, v in enumerate(vecs):
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            self._check(self._L.vr_set_global_data(self._h, k, _fptr(a), a.size))
+        if isinstance(data, TracingData) and data._scalars:
+            sc = np.ascontiguousarray(data._scalars, dtype=np.float32)
+            self._check(self._L.vr_set_global_scalars(self._h, _fptr(sc), sc.size))
+        self._globalData = data
+
+    def getGlobalData(self):
+        return getattr(self, "_globalData", None)
+
+    def getParticleTraceInfo(self, q):
+        pod = TraceInfoPOD()
+        self._check(self._L.vr_get_particle_trace_info(self._h, int(q), C.byref(pod)))
+        return pod
 
     def setUseWdist(self, on=True):
         """VIENNARAY_USE_WDIST as a run-time switch (rayTraceKernel.hpp:258-296)"""
@@ -380,7 +439,7 @@ class Trace:
             self._collect()
 
     def _collect(self):
-        labels = self._particle.getLocalDataLabels()
+        labels = [l for q in getattr(self, "_particles", [self._particle]) for l in q.getLocalDataLabels()]
         self._localData.setNumberOfVectorData(len(labels))
         for l, label in enumerate(labels):
             out = np.empty(self._n, dtype=np.float32)
