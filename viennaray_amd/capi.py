@@ -122,6 +122,8 @@ def load():
                           "(or __graft_entry__.build()); there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("VR_LIB_PATH") and not hasattr(L, name):
+                continue  # (an A/B run against an older build of the library: it lacks the newer entry points)
             fn = getattr(L, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args

@@ -1399,7 +1399,7 @@ static TraceParams batch_params(vr_context *c, const LaunchDesc &L, uint64_t fir
   // 0.1 15.62 -> 15.16 ms, C2 1.0 6.67 -> 6.62, plane 100^2 +-0; L2 hit rate of the C2 launch 74 -> 84 %, fabric reads
   // 9.0 -> 5.2 GB).  A structured scene is L2 resident anyway and its bins differ in cost — an eighth of the trench is
   // not an eighth of the work: trench3D +3 %, C5 +6 %: one queue.
-  const bool flat = L.traceMode == 1 || L.traceMode == 3;
+  const bool flat = L.traceMode == 3; // (the absorbing kernels have the single queue compiled in)
   p.numQueues = (flat && c->geo.numPrims > (1u << 17) && nbBatch >= 64u * VR_QUEUES * p.chunk) ? VR_QUEUES : 1u;
   if (const char *e = std::getenv("VR_QUEUES"))
     p.numQueues = std::atoi(e) >= (int)VR_QUEUES ? VR_QUEUES : 1u;

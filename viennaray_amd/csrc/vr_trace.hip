@@ -454,6 +454,11 @@ trace_kernel(const TraceParams p) {
   __shared__ unsigned cntS[8 * VR_BLOCK];
   __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier lists
   __shared__ uint4 candS[PQ_CREDIT ? (VR_BLOCK / 64) * VR_PQ_CANDS : 1]; // ... and candidate records (pq_credit)
+  // ... and, where the credits of a round carry different weights (the general kernels), one int64 sum per candidate
+  // and data label (two labels here; further ones are summed over the wave in registers)
+  constexpr bool PQ_SUMS = PQ_CREDIT && !ABSORB;
+  constexpr unsigned PQ_LAB = EXT ? 2u : 1u;
+  __shared__ unsigned long long candAccS[PQ_SUMS ? (VR_BLOCK / 64) * VR_PQ_CANDS * PQ_LAB : 1];
   // per-lane stack of the ordered walk, [entry][lane]; the absorbing flat-scene kernel walks rarely and keeps its
   // 8 waves per SIMD with a short LDS part (deeper entries: global slab)
   constexpr bool ORDERED = MODE != 1; // (MODE 1 walks rarely: it keeps the escape-link walk, one register of state)
@@ -556,7 +561,12 @@ trace_kernel(const TraceParams p) {
   const unsigned totalBins = p.numBins + (ovCount + p.binCap - 1) / p.binCap;
   unsigned curBin = 0, spanStart = 0, spanEnd = 0, curOff = 0, curCnt = 0, curBase = 0;
   unsigned spanCounts = 0; // lane i: ray count of bin spanStart + i
-  const unsigned myQueue = blockIdx.x & (p.numQueues - 1u); // (numQueues is 1 or 8)
+  // (only the general flat-scene kernel has the queues compiled in — it is the one they pay for, vr_api.cpp — the others
+  //  keep the single queue's code: MODE 1 with the bookkeeping: L2 hit rate 74 -> 84 % but 6.60 -> 6.83 ms from the
+  //  extra scalar spills of a kernel at 8 waves per SIMD)
+  constexpr bool MULTIQ = MODE == 3;
+  const unsigned numQueues = MULTIQ ? p.numQueues : 1u;
+  const unsigned myQueue = MULTIQ ? (blockIdx.x & (numQueues - 1u)) : 0u; // (numQueues is 1 or 8)
   unsigned qTried = 0;                      // queues this wave has found empty (wave-uniform)
   unsigned packetSkip = 0, packetFails = 0; // wave-uniform back-off of packet attempts
   unsigned pqSkip = 0, pqFails = 0;         // ... and of packet-query attempts
@@ -598,27 +608,40 @@ trace_kernel(const TraceParams p) {
             // with the others.  The rounds that follow each other on an XCD are then neighbours in space: the
             // primitive records one round pulled into the XCD's L2 serve the next (one global queue dealt
             // neighbouring spans to all eight L2s: 37 line misses per C2 round beyond its ray records).
-            unsigned lo = 0, hi = 0;
-            for (; qTried < p.numQueues; ++qTried) {
-              const unsigned q = (myQueue + qTried) & (p.numQueues - 1u);
-              const unsigned qLo = (unsigned)((unsigned long long)totalBins * q / p.numQueues);
-              const unsigned qHi = (unsigned)((unsigned long long)totalBins * (q + 1u) / p.numQueues);
+            if constexpr (!MULTIQ) {
               unsigned long long s = 0;
               if (lane == 0)
-                s = atomicAdd(p.workCounter + (size_t)q * VR_QUEUE_STRIDE, (unsigned long long)p.chunk);
+                s = atomicAdd(p.workCounter, (unsigned long long)p.chunk);
               s = bcast64(s);
-              if (s < (unsigned long long)(qHi - qLo)) {
-                lo = qLo + (unsigned)s;
-                hi = (lo + p.chunk < qHi) ? lo + p.chunk : qHi;
+              if (s >= totalBins) {
+                exhausted = true;
                 break;
               }
+              curBin = spanStart = (unsigned)s;
+              spanEnd = (unsigned)((s + p.chunk < totalBins) ? s + p.chunk : totalBins);
+            } else {
+              unsigned lo = 0, hi = 0;
+              for (; qTried < numQueues; ++qTried) {
+                const unsigned q = (myQueue + qTried) & (numQueues - 1u);
+                const unsigned qLo = (unsigned)((unsigned long long)totalBins * q / numQueues);
+                const unsigned qHi = (unsigned)((unsigned long long)totalBins * (q + 1u) / numQueues);
+                unsigned long long s = 0;
+                if (lane == 0)
+                  s = atomicAdd(p.workCounter + (size_t)q * VR_QUEUE_STRIDE, (unsigned long long)p.chunk);
+                s = bcast64(s);
+                if (s < (unsigned long long)(qHi - qLo)) {
+                  lo = qLo + (unsigned)s;
+                  hi = (lo + p.chunk < qHi) ? lo + p.chunk : qHi;
+                  break;
+                }
+              }
+              if (lo == hi) { // every queue is empty
+                exhausted = true;
+                break;
+              }
+              curBin = spanStart = lo;
+              spanEnd = hi;
             }
-            if (lo == hi) { // every queue is empty
-              exhausted = true;
-              break;
-            }
-            curBin = spanStart = lo;
-            spanEnd = hi;
             // the span's bin counts in one coalesced load (lane i <- bin spanStart + i; chunk <= 64)
             const unsigned bi = spanStart + lane;
             spanCounts = (bi < spanEnd && bi < p.numBins) ? p.binCount[bi] : 0u;
@@ -1028,6 +1051,15 @@ trace_kernel(const TraceParams p) {
           pz = mine ? __uint_as_float(cr.w) : pz;
         }
         const float dist = p.nbDist, dist2 = dist * dist;
+        // General kernels: the lanes crediting candidate c add their fixed-point weights to the wave's LDS sum of c
+        // (ds_add_u64: exact, any order) and afterwards lane c sends candidate c's total to HBM — ONE wave instruction
+        // of global atomics per round and label instead of one atomic per candidate and distinct weight.
+        unsigned long long *const candAcc = candAccS + (PQ_SUMS ? (tid >> 6) * (VR_PQ_CANDS * PQ_LAB) : 0u);
+        if (PQ_SUMS) {
+          for (unsigned k = lane; k < cands.count * PQ_LAB; k += 64u)
+            candAcc[k] = 0ull;
+          __builtin_amdgcn_wave_barrier();
+        }
         for (unsigned c = 0; c < cands.count; ++c) {
           DIAG(6);
           const uint4 cr = cands.rec[c];
@@ -1037,9 +1069,8 @@ trace_kernel(const TraceParams p) {
           near = near && ((dx * dx + dy * dy) + dz * dz) <= dist2;
           const bool sel = creditLane && (h.pos == q || (near && ((cands.local >> c) & 1ull)));
           if (EXT) {
-            // registry particles: the model's collide runs per lane with candidate q's own normal and id (its credits
-            // are only RECORDED per lane — a model may credit under any condition of its own — and then summed over the
-            // wave label by label: every selected lane adds to ONE address, q's entry of the label's plane)
+            // registry particles: the model's collide runs per lane with candidate q's own normal and id; its credits
+            // are RECORDED per lane (a model may credit under any condition of its own) and then added label by label
             if (ballot64(sel)) {
               const float4 n4 = prims[2 * (size_t)q + 1];
               float val[VR_MAX_LABELS];
@@ -1054,16 +1085,36 @@ trace_kernel(const TraceParams p) {
                                                  val[l] = l == label ? val[l] + v : val[l];
                                              });
 #pragma unroll
-              for (int l = 0; l < VR_MAX_LABELS; ++l)
-                if ((unsigned)l < p.numData)
+              for (int l = 0; l < VR_MAX_LABELS; ++l) {
+                if ((unsigned)l >= p.numData)
+                  break;
+                if ((unsigned)l < PQ_LAB) {
+                  if (sel)
+                    atomicAdd(&candAcc[c * PQ_LAB + (unsigned)l], weight_fx(val[l]));
+                } else {
                   credit_wave_sum(fluxAcc + (size_t)l * p.planeStride, q, sel ? weight_fx(val[l]) : 0ull);
+                }
+              }
             }
           } else if (ABSORB) {
             const unsigned long long m = ballot64(sel);
             if (m && lane == (unsigned)(__ffsll((long long)m) - 1))
               atomicAdd(&fluxAcc[q], (u64)__popcll(m) * 1099511627776ull); // unit weights: count x 2^40
           } else {
-            credit_aggregated(fluxAcc, sel, q, creditW);
+            if (sel)
+              atomicAdd(&candAcc[c], creditW);
+          }
+        }
+        if (PQ_SUMS) {
+          __builtin_amdgcn_wave_barrier();
+          if (lane < cands.count) {
+            const unsigned q = cands.rec[lane].x;
+#pragma unroll
+            for (unsigned l = 0; l < PQ_LAB; ++l) {
+              const unsigned long long v = *(volatile unsigned long long *)&candAcc[lane * PQ_LAB + l];
+              if (v && l < p.numData)
+                atomicAdd(&fluxAcc[(size_t)l * p.planeStride + q], v);
+            }
           }
         }
       }

@@ -84,12 +84,7 @@ struct TraceParams {
   uint32_t numData, planeStride; // data label l (TracingData vector l) lives at fluxAcc + l * planeStride
   // particle plug-ins (vr_particles.hpp): run-time kind of the extended kernel instantiation
   int32_t particleKind;
-  float meanFreePath;
-  float particleParams[8];       // vr_particle::params: the model's own parameters (ModelCtx::params)
-  // Trace::setGlobalData (rayTrace.hpp:137-145): read-only vectors indexed by the ORIGINAL primitive id, and scalars
-  const float *globalVec;        // [numGlobalVec][globalStride] or nullptr
-  const float *globalScalars;    // [numGlobalScalars] or nullptr
-  uint32_t numGlobalVec, globalStride, numGlobalScalars;
+  float reserved0, meanFreePath;
   int32_t useWdist;              // VIENNARAY_USE_WDIST crediting (rayTraceKernel.hpp:258-296)
   // sources other than SourceRandom: SourceGrid origins (raySourceGrid.hpp), or rays a host-side
   // Source callback produced (origin, direction, engine outputs it consumed)
@@ -98,10 +93,8 @@ struct TraceParams {
   float eeGrid;
   const float *hostOrg, *hostDir;
   const uint32_t *hostDraws;
-  const float *hostWeights;      // Source::getInitialRayWeight(idx) of a host-callback source (nullptr: 1, raySource.hpp:18)
   unsigned long long *counters;  // [8]
   unsigned long long *workCounter; // numQueues span cursors, VR_QUEUE_STRIDE words apart (a 128-byte line each)
-  uint32_t numQueues;              // 1, or 8: one queue of sort bins per XCD (vr_trace.hip, refill)
   unsigned long long *rngScratch; // [waves][312][64]
   // ray stream of the current batch: VR_BIN_CAP record slots per sort bin, then the
   // overflow region (rays whose bin was full), all in one array of 32-byte records
@@ -137,6 +130,15 @@ struct TraceParams {
   uint32_t walkExit;              // the per-lane walk of a round ends when fewer lanes than this are still walking
   uint32_t packetRatio;           // ... and it gives up when union visits > ratio x mean per-ray path
   uint32_t debugFlags;            // VR_DEBUG_FLAGS (timing experiments; 0 in production)
+  // ---- round 3 (appended: the kernels' scalar loads of the fields above keep their offsets and alignment — the
+  //      absorbing kernels sit at a fragile optimum of the register allocator) ----
+  uint32_t numQueues;              // 1, or 8: one queue of sort bins per XCD (vr_trace.hip, refill)
+  const float *hostWeights;        // Source::getInitialRayWeight(idx) of a host-callback source (nullptr: 1, raySource.hpp:18)
+  float particleParams[8];         // vr_particle::params: the model's own parameters (ModelCtx::params)
+  // Trace::setGlobalData (rayTrace.hpp:137-145): read-only vectors indexed by the ORIGINAL primitive id, and scalars
+  const float *globalVec;          // [numGlobalVec][globalStride] or nullptr
+  const float *globalScalars;      // [numGlobalScalars] or nullptr
+  uint32_t numGlobalVec, globalStride, numGlobalScalars;
 };
 
 // device-side scene setup (vr_setup.hip)

@@ -349,7 +349,8 @@ class Trace:
             w = np.ascontiguousarray(weights, dtype=np.float32)
             assert w.size == o.shape[0]
             self._check(self._L.vr_set_host_ray_weights(self._h, _fptr(w), w.size))
-        self._check(self._L.vr_set_source_area(self._h, float(sourceArea) if sourceArea is not None else 0.0))
+        if sourceArea is not None or hasattr(self._L, "vr_set_source_area"):
+            self._check(self._L.vr_set_source_area(self._h, float(sourceArea) if sourceArea is not None else 0.0))
 
     def reserveRays(self, n):
         """Size the HBM ray stream for applies of up to n rays (apply() per time step with a growing count)."""
