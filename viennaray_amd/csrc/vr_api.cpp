@@ -1967,9 +1967,10 @@ int vr_smooth_flux(vr_context *c, float *flux, uint32_t n, int numNeighbors) {
     return fail(c, VR_E_INVALID, "vr_smooth_flux: bad argument");
   if (c->geo.geo != 0 || numNeighbors < 1)
     return VR_OK;
-  // device path: the geometry's own neighbourhood (numNeighbors == 1, what every reference
-  // example asks for) is resident with the device-built scene; no download of the CSR
-  if (numNeighbors == 1 && c->haveSetup && !c->geometryDirty && !std::getenv("VR_HOST_SMOOTH")) {
+  // device path: the geometry's own neighbourhood (numNeighbors == 1, what every reference example asks for) is
+  // resident with the device-built scene; a wider one (k > 1) is a range query of radius k * 2 r over the resident BVH,
+  // fused with the averaging.  No download of any neighbourhood.
+  if (c->haveSetup && !c->geometryDirty && !std::getenv("VR_HOST_SMOOTH")) {
     VR_HIP(c, hipSetDevice(c->device));
     DevBuf<float> dIn, dOut;
     DevBuf<uint32_t> dOv;
@@ -1979,8 +1980,12 @@ int vr_smooth_flux(vr_context *c, float *flux, uint32_t n, int numNeighbors) {
     uint32_t ov = 0;
     VR_HIP(c, hipMemcpyAsync(dIn.p, flux, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     VR_HIP(c, hipMemsetAsync(dOv.p, 0, 4, c->stream));
-    VR_HIP(c, launch_smooth_flux(dIn.p, dOut.p, c->dNormal3.p, c->dNbOff.p, c->dNbIds.p, c->dOrder.p,
-                                 c->dLeafOfOrig.p, n, dOv.p, c->stream));
+    if (numNeighbors == 1)
+      VR_HIP(c, launch_smooth_flux(dIn.p, dOut.p, c->dNormal3.p, c->dNbOff.p, c->dNbIds.p, c->dOrder.p,
+                                   c->dLeafOfOrig.p, n, dOv.p, c->stream));
+    else
+      VR_HIP(c, launch_smooth_wide(dIn.p, dOut.p, c->dNormal3.p, c->lastSetup, numNeighbors * 2 * c->geo.diskRadius,
+                                   dOv.p, c->stream));
     VR_HIP(c, hipMemcpyAsync(&ov, dOv.p, 4, hipMemcpyDeviceToHost, c->stream));
     VR_HIP(c, hipStreamSynchronize(c->stream));
     if (ov == 0) {

@@ -28,6 +28,8 @@ hipError_t launch_bvh_check(const SetupParams &s, unsigned *bad, hipStream_t st)
 hipError_t launch_smooth_flux(const float *fluxIn, float *fluxOut, const float *normal3, const uint32_t *nbOff,
                               const uint32_t *nbIds, const uint32_t *order, const uint32_t *leafOfOrig, unsigned n,
                               unsigned *overflow, hipStream_t st);
+hipError_t launch_smooth_wide(const float *fluxIn, float *fluxOut, const float *normal3, const SetupParams &s, float dist,
+                              unsigned *overflow, hipStream_t st);
 hipError_t launch_quantize_nodes(const float *nodes, unsigned numNodes, const float *base3, const float *scale3,
                                  uint32_t *qnodes, uint32_t *pnodes, hipStream_t st);
 hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st);

@@ -31,8 +31,10 @@ int vr_rccl_unique_id(char id[VR_RCCL_UNIQUE_ID_BYTES]) {
 }
 
 int vr_rccl_init_rank(vr_rccl_comm **out, const char id[VR_RCCL_UNIQUE_ID_BYTES], int rank, int world) {
-  if (!out || !id || world < 1 || rank < 0 || rank >= world)
+  if (!out || !id || world < 1 || rank < 0 || rank >= world) {
+    g_err = "vr_rccl_init_rank: bad argument (out, id, 0 <= rank < world)";
     return -1;
+  }
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof(u));
   vr_rccl_comm *c = new vr_rccl_comm();
@@ -56,8 +58,10 @@ void vr_rccl_destroy(vr_rccl_comm *c) {
 
 int vr_rccl_allreduce(void *user, void *devInt64, size_t count, void *hipStream) {
   vr_rccl_comm *c = static_cast<vr_rccl_comm *>(user);
-  if (!c || !c->comm)
+  if (!c || !c->comm) {
+    g_err = "vr_rccl_allreduce: no communicator (vr_rccl_init_rank)";
     return -1;
+  }
   ncclResult_t r = ncclAllReduce(devInt64, devInt64, count, ncclInt64, ncclSum, c->comm, (hipStream_t)hipStream);
   if (r != ncclSuccess) {
     g_err = ncclGetErrorString(r);

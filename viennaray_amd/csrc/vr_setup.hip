@@ -686,6 +686,83 @@ __global__ void smooth_flux_kernel(const float *fluxIn, float *fluxOut, const fl
   fluxOut[i] = vv / sum;
 }
 
+// smoothFlux(flux, k > 1) (rayTraceDisk.hpp:146-193: a PointNeighborhood of radius k * 2 r, built for the call): the
+// neighbourhood is not stored — every thread runs the range query of nb_kernel with the wider radius over the resident
+// BVH, keeps the ids it finds (ascending original id, like the host path: float addition is ordered) and averages.
+constexpr unsigned SMOOTH_WIDE_MAX = 128;
+__global__ void smooth_wide_kernel(const float *fluxIn, float *fluxOut, const float *normal3, SetupParams s, float dist,
+                                   unsigned *overflow) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s.n)
+    return;
+  const float4 *nodes = reinterpret_cast<const float4 *>(s.nodes);
+  const float px = s.points3[3 * (size_t)i], py = s.points3[3 * (size_t)i + 1], pz = s.points3[3 * (size_t)i + 2];
+  const float dist2 = dist * dist;
+  const float qlo[3] = {px - dist, py - dist, s.D == 2 ? -FLT_MAX : pz - dist};
+  const float qhi[3] = {px + dist, py + dist, s.D == 2 ? FLT_MAX : pz + dist};
+  unsigned ids[SMOOTH_WIDE_MAX];
+  unsigned cnt = 0;
+  bool over = false;
+  unsigned node = 0;
+  while (node != VR_END) {
+    const float4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
+    const unsigned link = __float_as_uint(a.w), esc = __float_as_uint(b.w);
+    // (the boxes are the discs' boxes: a disc's box contains its centre, and every centre within `dist` lies in the query box)
+    const bool hit = a.x <= qhi[0] && b.x >= qlo[0] && a.y <= qhi[1] && b.y >= qlo[1] && a.z <= qhi[2] && b.z >= qlo[2];
+    if (hit && (link & VR_LEAF)) {
+      const unsigned first = link & VR_LEAF_FIRST_MASK, num = (link >> 27) & 15u;
+      for (unsigned k = 0; k < num; ++k) {
+        const unsigned o = s.order[first + k];
+        if (o == i)
+          continue;
+        const float dx = px - s.points3[3 * (size_t)o], dy = py - s.points3[3 * (size_t)o + 1],
+                    dz = pz - s.points3[3 * (size_t)o + 2];
+        bool near = fabsf(dx) <= dist && fabsf(dy) <= dist && (s.D == 2 || fabsf(dz) <= dist);
+        near = near && ((dx * dx + dy * dy) + dz * dz) <= dist2;
+        if (!near)
+          continue;
+        if (cnt == SMOOTH_WIDE_MAX) {
+          over = true;
+          continue;
+        }
+        unsigned k2 = cnt++;
+        while (k2 > 0 && ids[k2 - 1] > o) { // insertion sort by original id
+          ids[k2] = ids[k2 - 1];
+          --k2;
+        }
+        ids[k2] = o;
+      }
+      node = esc;
+    } else {
+      node = hit ? link : esc;
+    }
+  }
+  if (over) {
+    atomicAdd(overflow, 1u);
+    fluxOut[i] = fluxIn[i];
+    return;
+  }
+  const float nx = normal3[3 * (size_t)i], ny = normal3[3 * (size_t)i + 1], nz = normal3[3 * (size_t)i + 2];
+  float vv = fluxIn[i], sum = 1.f;
+  for (unsigned k = 0; k < cnt; ++k) {
+    const unsigned o = ids[k];
+    const float w = (nx * normal3[3 * (size_t)o] + ny * normal3[3 * (size_t)o + 1]) + nz * normal3[3 * (size_t)o + 2];
+    if (w > 0.f) {
+      vv += fluxIn[o] * w;
+      sum += w;
+    }
+  }
+  fluxOut[i] = vv / sum;
+}
+
+hipError_t launch_smooth_wide(const float *fluxIn, float *fluxOut, const float *normal3, const SetupParams &s, float dist,
+                              unsigned *overflow, hipStream_t st) {
+  if (s.n == 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(smooth_wide_kernel, dim3((s.n + 127) / 128), dim3(128), 0, st, fluxIn, fluxOut, normal3, s, dist, overflow);
+  return hipGetLastError();
+}
+
 hipError_t launch_smooth_flux(const float *fluxIn, float *fluxOut, const float *normal3, const uint32_t *nbOff,
                               const uint32_t *nbIds, const uint32_t *order, const uint32_t *leafOfOrig, unsigned n,
                               unsigned *overflow, hipStream_t st) {
