@@ -127,6 +127,20 @@ int vr_set_particle(vr_context *ctx, const vr_particle *particle);
  * vr_get_flux_data / vr_num_data; particles with the same source distribution share one generator pass (the rays
  * of ray index idx are the same for them).  runNumber advances once.                                         */
 int vr_set_particles(vr_context *ctx, const vr_particle *particles, uint32_t n);
+/* OPEN registration (the reference's GPU path registers user callables per particle at run time,
+ * gpu/raygCallableConfig.hpp:7-18, gpu/raygTrace.hpp:163-248): `source` is HIP source text defining
+ *     struct VrUserModel { static constexpr int kNumData; static constexpr bool kNeedsFull;
+ *                          __device__ static float sticking(const ModelCtx &, unsigned primID, float base);
+ *                          template <int D> __device__ static V3 reflect(const ModelCtx &, const V3 &rayDir, const V3 &n, Rng &, unsigned &);
+ *                          template <class Credit> __device__ static void collide(const ModelCtx &, float w, const V3 &rayDir,
+ *                                                                               const V3 &n, unsigned primID, Credit &&credit); };
+ * (usually derived from a built-in model of viennaray_amd/csrc/vr_particles.hpp, overriding one member).  The library
+ * compiles the extended trace kernels around it for gfx950 (hipcc --genco, cached by content under VR_CACHE_DIR or
+ * /tmp) and loads the code object; *kind (>= VR_PARTICLE_USER_BASE) is then a valid vr_particle::kind of this context.
+ * numData = VrUserModel::kNumData (1..4); flags: VR_MODEL_NEEDS_FULL = VrUserModel::kNeedsFull (the model is to be
+ * combined with WDIST crediting / mean-free-path scattering, or brings heavy code of its own).  Needs hipcc at run time. */
+enum { VR_PARTICLE_USER_BASE = 1000, VR_MODEL_NEEDS_FULL = 1 };
+int vr_register_particle_model(vr_context *ctx, const char *name, const char *source, int numData, int flags, int32_t *kind);
 /* Trace::setGlobalData (rayTrace.hpp:137-145; handed to every surfaceCollision / surfaceReflection,
  * rayParticle.hpp:21-81): vector `vecIdx` (indexed by primitive id) and the scalars of the caller's TracingData,
  * copied to HBM and readable by the device particle models.  data == NULL drops the vector and those behind it. */

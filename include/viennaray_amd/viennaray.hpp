@@ -847,6 +847,34 @@ public:
   }
 };
 
+// A particle whose device model was registered at run time (Trace::registerParticleModel — the counterpart of the
+// reference's GPU path naming user callables per particle, gpu/raygCallableConfig.hpp:7-18): `kind` is what the
+// registration returned, `params` go to the model as ModelCtx::params.  The host virtuals keep the no-op defaults of
+// Particle<>: the per-hit logic IS the device model.
+template <typename NumericType, int D>
+class UserModelParticle : public Particle<UserModelParticle<NumericType, D>, NumericType> {
+  const int kind_;
+  const NumericType stickingProbability_, sourcePower_;
+  const std::vector<std::string> dataLabels_;
+  std::array<float, 8> params_{};
+
+public:
+  UserModelParticle(int kind, NumericType stickingProbability, std::vector<std::string> dataLabels,
+                    NumericType sourcePower = NumericType(1), const std::vector<float> &params = {})
+      : kind_(kind), stickingProbability_(stickingProbability), sourcePower_(sourcePower), dataLabels_(std::move(dataLabels)) {
+    for (size_t k = 0; k < params.size() && k < params_.size(); ++k)
+      params_[k] = params[k];
+  }
+  NumericType getSourceDistributionPower() const final { return sourcePower_; }
+  [[nodiscard]] std::vector<std::string> getLocalDataLabels() const final { return dataLabels_; }
+  bool deviceModel(vr_particle &pod) const final {
+    pod = vr_particle{kind_, (float)stickingProbability_, (float)sourcePower_, 0, nullptr, nullptr, 0.f, -1.f, {}};
+    for (size_t k = 0; k < params_.size(); ++k)
+      pod.params[k] = params_[k];
+    return true;
+  }
+};
+
 // ---- Trace<T,D> ----------------------------------------------------------------------
 template <class NumericType, int D> class Trace {
 public:
@@ -945,6 +973,15 @@ public:
     particleOnDevice_ = pParticle_->deviceModel(pod);
     if (ctx_ && particleOnDevice_)
       check(vr_set_particle(ctx_, &pod));
+  }
+  /// NOT in the reference's CPU Trace: compile a device particle model at run time (vr_register_particle_model: HIP source
+  /// of `struct VrUserModel`, see viennaray_amd/csrc/vr_particles.hpp) and get the kind id for a UserModelParticle.
+  /// Returns -1 (and sets TraceInfo.error) if the model does not compile.
+  int registerParticleModel(const std::string &name, const std::string &source, int numData = 1, bool needsFull = false) {
+    int32_t kind = -1;
+    if (ctx_)
+      check(vr_register_particle_model(ctx_, name.c_str(), source.c_str(), numData, needsFull ? VR_MODEL_NEEDS_FULL : 0, &kind));
+    return kind;
   }
   /// NOT in the reference's CPU Trace (its gpu::Trace keeps a particle list, gpu/raygTrace.hpp:163-248): several
   /// particles traced in ONE apply() — the same seed for all, one generator pass per source distribution;

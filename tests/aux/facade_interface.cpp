@@ -233,6 +233,33 @@ int main() {
     VC_TEST_ASSERT(a > 0 && b > 0 && a != b);
     std::printf("particle list: sum neutral %g, sum ion %g\n", a, b);
   }
+  { // a device model registered at run time: a diffuse particle that credits weight x height of the primitive it meets
+    // (reads nothing global) — compiled by the library, then traced like a built-in one
+    const char *src = "struct VrUserModel : ModelDiffuse {\n"
+                      "  template <class Credit>\n"
+                      "  __device__ static void collide(const ModelCtx &m, float w, const V3 &, const V3 &, unsigned, Credit &&credit) {\n"
+                      "    credit(0, w * m.params[0]);\n"
+                      "  }\n"
+                      "};\n";
+    const int kind = rayTracer.registerParticleModel("scaled", src, 1);
+    VC_TEST_ASSERT(kind >= VR_PARTICLE_USER_BASE && !rayTracer.getRayTraceInfo().error);
+    rayTracer.setNumberOfRaysPerPoint(200); // (the two applies below use different seeds: enough rays for a 1 % comparison)
+    rayTracer.setParticleType(std::make_unique<UserModelParticle<NumericType, D>>(kind, NumericType(0.5), std::vector<std::string>{"scaled"},
+                                                                                 NumericType(1), std::vector<float>{2.5f}));
+    rayTracer.apply();
+    const std::vector<NumericType> scaled = rayTracer.getLocalData().getVectorData("scaled");
+    rayTracer.setParticleType(std::make_unique<DiffuseParticle<NumericType, D>>(NumericType(0.5), "plain"));
+    rayTracer.apply();
+    const auto &plain = rayTracer.getLocalData().getVectorData("plain");
+    double a = 0, b = 0;
+    for (size_t k = 0; k < plain.size(); ++k) {
+      a += scaled[k];
+      b += plain[k];
+    }
+    VC_TEST_ASSERT(b > 0 && std::fabs(a / b - 2.5) < 0.05);
+    std::printf("run-time model: sum %g = %.3f x the plain particle's %g\n", a, a / b, b);
+    rayTracer.setNumberOfRaysPerPoint(10);
+  }
   { // a host-only user particle is refused, loudly
     rayTracer.setParticleType(std::make_unique<HostOnlyParticle<NumericType>>());
     rayTracer.apply();

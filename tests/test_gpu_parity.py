@@ -3,6 +3,8 @@ the same seeded inputs.  Integer work (RNG words, ray origins AND directions, hi
 ids, every TraceInfo counter, sticking-1 flux) is bit-exact; fractional-weight flux
 differs only by float summation order and is compared by L2-relative error against
 the tolerance BASELINE.json's north_star states (1e-4; measured <= 3e-7)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1425,6 +1427,94 @@ def test_multi_particle_apply_shares_the_generator_pass(geom):
     t.setRunNumber(1)
     t.apply()
     assert t.numData() == 1 and (t.getLocalData().getVectorData("a") == ld.getVectorData(0)).all()
+
+
+USER_TWO_LABELS = """
+// the registry's two-label particle, written as a caller would write it: DiffuseParticle + a second label
+struct VrUserModel : ModelDiffuse {
+  static constexpr int kNumData = 2;
+  template <class Credit>
+  __device__ static void collide(const ModelCtx &, float w, const V3 &rayDir, const V3 &n, unsigned, Credit &&credit) {
+    credit(0, w);
+    const float cosTheta = -vdot(rayDir, n);
+    credit(1, w * fmaxf(cosTheta, 0.f));
+  }
+};
+"""
+USER_COVERAGE = """
+// coverage-dependent sticking with the coverage vector's index in params[0] and a gain in params[1]
+struct VrUserModel : ModelDiffuse {
+  __device__ static float sticking(const ModelCtx &m, unsigned primID, float base) {
+    return base * (1.f - m.global.vector((unsigned)m.params[0], primID)) * m.params[1];
+  }
+};
+"""
+
+
+@pytest.mark.parametrize("geom", ["trench3d", "plane", "trench2d", "mesh"])
+def test_particle_model_registered_at_run_time(geom, tmp_path, monkeypatch):
+    """OPEN registration (gpu/raygCallableConfig.hpp:7-18: the reference's GPU path registers user callables per particle):
+    the SOURCE of a model is compiled at run time (hipcc --genco), loaded as a code object and traced.  Two user models
+    that restate built-in ones give the built-in particles' flux bit for bit, on every kernel variant (general, flat
+    scene with packet-query crediting, LDS-resident scene, triangles) — alone and inside a particle list."""
+    monkeypatch.setenv("VR_CACHE_DIR", str(tmp_path))
+
+    def tracer():
+        if geom == "plane":
+            pts, nrm = vr.io.plane_grid(70, 1.0)
+            t = vr.TraceDisk(3)
+            t.setGeometry(pts, nrm, 1.0)
+            t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+        else:
+            t, _ = _plugin_pair(geom, vr.DiffuseParticle(0.5, "x"), po.DIFFUSE, 0.5)
+        t.setNumberOfRaysPerPoint(60)
+        t.setRngSeed(31)
+        return t
+    t = tracer()
+    k2 = t.registerParticleModel(USER_TWO_LABELS, numData=2, name="twoLabels")
+    kc = t.registerParticleModel(USER_COVERAGE, numData=1, name="coverage")
+    assert k2 >= 1000 and kc == k2 + 1
+    assert any(f.endswith(".hsaco") for f in os.listdir(tmp_path))
+    cov = np.random.default_rng(3).uniform(0, 1, t._n).astype(np.float32)
+    t.setGlobalData([cov])
+
+    def run(particles):
+        t.setParticleTypes(particles)
+        t.setRunNumber(1)
+        t.apply()
+        ld = t.getLocalData()
+        return t.traceMode(), info_dict(t), [ld.getVectorData(k).copy() for k in range(t.numData())]
+    m_user, i_user, f_user = run([vr.UserModelParticle(k2, 0.3, ["flux", "cos"])])
+    m_ref, i_ref, f_ref = run([vr.DiffuseCosineParticle(0.3, "flux", "cos")])
+    assert m_user == m_ref == {"trench3d": 0, "plane": 3, "trench2d": 4, "mesh": 0}[geom]
+    assert i_user == i_ref and all((a == b).all() for a, b in zip(f_user, f_ref))
+    _, i_user, f_user = run([vr.UserModelParticle(kc, 0.8, ["flux"], params=[0.0, 1.0])])
+    _, i_ref, f_ref = run([vr.CoverageStickingParticle(0.8, "flux", 0)])
+    assert i_user == i_ref and (f_user[0] == f_ref[0]).all()
+    _, i_half, f_half = run([vr.UserModelParticle(kc, 0.8, ["flux"], params=[0.0, 0.5])])   # the model's own parameter
+    assert geom == "plane" or i_half != i_ref     # (on the plane every reflected ray leaves: sticking changes nothing there)
+    # a list mixing run-time and built-in models: one apply, every label in place
+    _, i_mix, f_mix = run([vr.UserModelParticle(k2, 0.3, ["flux", "cos"]), vr.DiffuseParticle(0.4, "d"),
+                           vr.UserModelParticle(kc, 0.8, ["c"], params=[0.0, 1.0])])
+    assert len(f_mix) == 4 and (f_mix[3] == f_ref[0]).all()
+    _, _, f_two = run([vr.DiffuseCosineParticle(0.3, "flux", "cos")])
+    assert (f_mix[0] == f_two[0]).all() and (f_mix[1] == f_two[1]).all()
+    # a second context finds the code objects in the cache (no second compile: the directory does not grow)
+    before = sorted(os.listdir(tmp_path))
+    t2 = tracer()
+    assert t2.registerParticleModel(USER_TWO_LABELS, numData=2) >= 1000 and sorted(os.listdir(tmp_path)) == before
+
+
+def test_particle_model_that_does_not_compile_is_refused(tmp_path, monkeypatch):
+    monkeypatch.setenv("VR_CACHE_DIR", str(tmp_path))
+    t = vr.TraceDisk(3)
+    with pytest.raises(vr.VrError) as e:
+        t.registerParticleModel("struct VrUserModel : ModelDiffuse { static constexpr int kNumData = nonsense; };", numData=1)
+    assert "did not compile" in str(e.value) and "nonsense" in str(e.value)
+    with pytest.raises(vr.VrError):   # kNumData must be what the caller announced
+        t.registerParticleModel("struct VrUserModel : ModelDiffuse { static constexpr int kNumData = 2; };", numData=1)
+    with pytest.raises(vr.VrError):   # an unregistered kind
+        t.setParticleType(vr.UserModelParticle(1000, 0.5, ["x"]))
 
 
 def test_registry_particles_use_packet_query_crediting_on_flat_scenes(monkeypatch):

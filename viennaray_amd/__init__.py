@@ -6,6 +6,6 @@ its Python host mirror (used by bench.py and the parity tests).
 from .capi import VrError, load, device_available, LIB_PATH  # noqa: F401
 from .trace import (BoundaryCondition, TraceDirection, NormalizationType,  # noqa: F401
                     TracingDataMergeEnum, DiffuseParticle, SpecularParticle,
-                    ConedCosineParticle, DiffuseCosineParticle, CoverageStickingParticle, SourceGrid,
+                    ConedCosineParticle, DiffuseCosineParticle, CoverageStickingParticle, UserModelParticle, SourceGrid,
                     TracingData, Trace, TraceDisk, TraceTriangle)
 from . import io  # noqa: F401

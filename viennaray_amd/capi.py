@@ -59,6 +59,7 @@ SIGNATURES = {
     "vr_set_primary_direction": (C.c_int, [_vp, _fp]),
     "vr_set_particle": (C.c_int, [_vp, C.POINTER(ParticlePOD)]),
     "vr_set_particles": (C.c_int, [_vp, C.POINTER(ParticlePOD), C.c_uint32]),
+    "vr_register_particle_model": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, _i32p]),
     "vr_set_global_data": (C.c_int, [_vp, C.c_uint32, _fp, C.c_uint32]),
     "vr_set_global_scalars": (C.c_int, [_vp, _fp, C.c_uint32]),
     "vr_get_particle_trace_info": (C.c_int, [_vp, C.c_uint32, C.POINTER(TraceInfoPOD)]),

@@ -197,7 +197,15 @@ struct ModelCoverageSticking : ModelDiffuse {
 template <class... M> struct ModelList {
   static constexpr int size = (int)sizeof...(M);
 };
+#ifdef VR_USER_MODEL_FILE
+// a model registered at run time (vr_register_particle_model): the caller's source defines `struct VrUserModel` with the
+// shape above — typically derived from one of the models here — and becomes the last entry of this module's registry
+#include VR_USER_MODEL_FILE
+using Registry = ModelList<ModelDiffuse, ModelSpecular, ModelConedCosine, ModelDiffuseCosine, ModelCoverageSticking, VrUserModel>;
+#else
 using Registry = ModelList<ModelDiffuse, ModelSpecular, ModelConedCosine, ModelDiffuseCosine, ModelCoverageSticking>;
+#endif
+constexpr int VR_BUILTIN_MODELS = 5; // (a run-time model is number VR_BUILTIN_MODELS inside its own code object)
 
 template <int I, class List> struct ModelAt;
 template <int I, class M0, class... M> struct ModelAt<I, ModelList<M0, M...>> : ModelAt<I - 1, ModelList<M...>> {};

@@ -33,6 +33,7 @@ namespace vr {
 // fixed-point weight: 2^40 per unit (order-independent integer accumulation)
 __device__ __forceinline__ u64 weight_fx(float w) { return (u64)((double)w * 1099511627776.0 + 0.5); }
 
+#ifndef VR_USER_MODULE // (a run-time compiled particle module holds trace kernels only, see the end of the file)
 // ---------------------------------------------------------------------------
 // source sampling (raySourceRandom.hpp:25-116)
 // ---------------------------------------------------------------------------
@@ -328,6 +329,8 @@ __global__ __launch_bounds__(VR_BLOCK) void scan_add_kernel(unsigned *data, unsi
     if (base + k < n)
       data[base + k] += off;
 }
+
+#endif // VR_USER_MODULE
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned v) {
   unsigned long long s = v;
@@ -1155,6 +1158,7 @@ trace_kernel(const TraceParams p) {
   }
 }
 
+#ifndef VR_USER_MODULE
 // ---------------------------------------------------------------------------
 // host-callable launchers
 // ---------------------------------------------------------------------------
@@ -1385,5 +1389,23 @@ hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, un
                      outAcc);
   return hipGetLastError();
 }
+
+#else // VR_USER_MODULE
+// ---------------------------------------------------------------------------
+// A particle model registered at RUN TIME (vr_register_particle_model, include/viennaray_amd.h): the library writes a
+// translation unit that defines VR_USER_MODEL_FILE (the caller's model source: `struct VrUserModel`, appended to the
+// registry in vr_particles.hpp) and includes this file; `hipcc --genco` turns it into a code object holding the
+// extended trace kernels with that model compiled in.  The host finds them by their mangled names.
+// ---------------------------------------------------------------------------
+static_assert(VrUserModel::kNumData >= 1 && VrUserModel::kNumData <= VR_MAX_LABELS, "a model has 1 .. VR_MAX_LABELS data labels");
+static_assert(VrUserModel::kNumData == VR_USER_NUM_DATA, "kNumData differs from the count given at registration");
+constexpr int VR_USER_P = VrUserModel::kNeedsFull ? P_EXT_FULL : P_EXT;
+#define VR_INST(DD, GG, MM) template __global__ void trace_kernel<DD, GG, VR_USER_P, MM>(const TraceParams);
+VR_INST(2, 0, 0) VR_INST(2, 0, 4) VR_INST(2, 1, 0) VR_INST(2, 1, 4)
+VR_INST(3, 0, 0) VR_INST(3, 0, 4) VR_INST(3, 1, 0) VR_INST(3, 1, 4)
+#undef VR_INST
+template __global__ void trace_kernel<2, 0, P_EXT, VrUserModel::kNeedsFull ? 0 : 3>(const TraceParams);
+template __global__ void trace_kernel<3, 0, P_EXT, VrUserModel::kNeedsFull ? 0 : 3>(const TraceParams);
+#endif // VR_USER_MODULE
 
 } // namespace vr

@@ -141,6 +141,27 @@ class CoverageStickingParticle:
         return [self.dataLabel]
 
 
+class UserModelParticle:
+    """A particle whose device model was registered at run time (Trace.registerParticleModel): `kind` is what the
+    registration returned, `dataLabels` one label per data label of the model, `params` the model's parameters."""
+
+    def __init__(self, kind, stickingProbability, dataLabels, sourcePower=1.0, params=(), materialSticking=None,
+                 meanFreePath=-1.0):
+        self.kind = int(kind)
+        self.stickingProbability = float(stickingProbability)
+        self.dataLabels = list(dataLabels)
+        self.sourcePower = float(sourcePower)
+        self.params = [float(v) for v in params]
+        self.materialSticking = dict(materialSticking or {})
+        self.meanFreePath = float(meanFreePath)
+
+    def getSourceDistributionPower(self):
+        return self.sourcePower
+
+    def getLocalDataLabels(self):
+        return list(self.dataLabels)
+
+
 class SourceGrid:
     """raySourceGrid.hpp: explicit ray origins (createSourceGrid, rayUtil.hpp:564-611); the direction
     comes from the particle's cosine power."""
@@ -298,6 +319,13 @@ class Trace:
         self._particle = particles[0]
         self._particles = particles
         del keep
+
+    def registerParticleModel(self, source, numData=1, needsFull=False, name="user"):
+        """vr_register_particle_model: HIP source of `struct VrUserModel` -> the kind id of a UserModelParticle"""
+        k = C.c_int32(0)
+        self._check(self._L.vr_register_particle_model(self._h, name.encode(), source.encode(), int(numData),
+                                                       1 if needsFull else 0, C.byref(k)))
+        return int(k.value)
 
     def setGlobalData(self, data):
         """rayTrace.hpp:141: a TracingData (or a list of per-primitive arrays) the device particle models may read"""
