@@ -1517,6 +1517,32 @@ def test_particle_model_that_does_not_compile_is_refused(tmp_path, monkeypatch):
         t.setParticleType(vr.UserModelParticle(1000, 0.5, ["x"]))
 
 
+@pytest.mark.parametrize("n,flat", [(21, "1"), (21, "0"), (100, "0"), (8, "1")])
+def test_two_label_particle_on_coarse_planes_matches_oracle(n, flat, monkeypatch):
+    """Coarse flat scenes are where a wave's credits pile up on a few disks (merged per disk and weight, or summed over the
+    wave): the two-label registry particle against the oracle on P(21) / P(100) / P(8) with REFLECTIVE walls, through the
+    packet-query crediting (MODE 3), the per-lane neighbour loop (MODE 0) and the LDS-resident kernel (MODE 4).
+    Analytic check: a cosine source makes label 1 / label 0 = E[cos] = 2/3."""
+    monkeypatch.setenv("VR_GENERAL_FLAT", flat)
+    pts, nrm = vr.io.plane_grid(n, 0.5)
+    t = vr.TraceDisk(3)
+    t.setGeometry(pts, nrm, 0.5)
+    t.setParticleType(vr.DiffuseCosineParticle(0.5, "flux", "cos"))
+    o = po.Oracle()
+    o.set_disks(pts, nrm, 0.5, 3)
+    o.set_particle_ex(po.DIFFUSE_COSINE, 0.5, 1.0, 0.0, -1.0)
+    for x, m in ((t, "setNumberOfRaysPerPoint"), (o, "set_num_rays_per_point")):
+        getattr(x, m)(400)
+    t.setRngSeed(21)
+    o.set_rng_seed(21)
+    o.set_lazy_rng(True)
+    err, gi = compare(t, o)
+    assert t.traceMode() == (4 if n == 8 else (3 if flat == "1" else 0))
+    a, b = t.getLocalData().getVectorData("cos"), o.flux_data(1)
+    assert l2_rel(a, b) <= 5e-6
+    assert abs(float(a.sum()) / float(t.getLocalData().getVectorData("flux").sum()) - 2.0 / 3.0) < 0.01
+
+
 def test_registry_particles_use_packet_query_crediting_on_flat_scenes(monkeypatch):
     """the two-label particle on P(100): MODE 3 (packet-query crediting of registry particles) gives what MODE 0 gives"""
     pts, nrm = vr.io.plane_grid(100, 1.0)
