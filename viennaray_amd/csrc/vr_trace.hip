@@ -428,9 +428,18 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 // MODE 4: MODE 0 for scenes of a few hundred primitives (2-D simulations): pair nodes, primitive records,
 // neighbourhood and flux accumulators are staged in LDS (VR_SMALL_LDS bytes per block) and every access of the
 // round but the ray records stays there; no packets (a per-lane walk over LDS nodes is cheaper than their set-up).
+#ifndef VR_WAVE_COUNTERS
+#define VR_WAVE_COUNTERS 0
+#endif
+#ifndef VR_GENERAL_WAVES
+#define VR_GENERAL_WAVES 6 // waves per SIMD of the general kernel (MODE 0)
+#endif
+#ifndef VR_FLAT_WAVES
+#define VR_FLAT_WAVES 5    // ... of the general flat-scene kernel (MODE 3)
+#endif
 template <int D, int GEO, int PARTICLE, int MODE_>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
-__attribute__((amdgpu_waves_per_eu(MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? 5 : (MODE_ == 4 ? 5 : 6))), MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? 5 : (MODE_ == 4 ? 5 : 6)))))) void
+__attribute__((amdgpu_waves_per_eu(MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? 5 : VR_GENERAL_WAVES))), MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? 5 : VR_GENERAL_WAVES)))))) void
 trace_kernel(const TraceParams p) {
   constexpr bool SMALL = MODE_ == 4;
   constexpr int MODE = SMALL ? 0 : MODE_;
@@ -454,7 +463,11 @@ trace_kernel(const TraceParams p) {
   constexpr bool CARRY = MODE != 1;
   __shared__ float wallS[96];
   // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
-  __shared__ unsigned cntS[8 * VR_BLOCK];
+  // The general kernels count five of the eight events per WAVE (a wave-uniform register += popcount of the lanes
+  // that reach the count) and keep per-lane LDS words only for the three that are added as values or passed by
+  // reference: 5 KB of LDS less per block — what stood between the general kernel and a 7th wave per SIMD.
+  constexpr bool WAVEC = (VR_WAVE_COUNTERS != 0) && !ABSORB;
+  __shared__ unsigned cntS[(WAVEC ? 3 : 8) * VR_BLOCK];
   __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier lists
   __shared__ uint4 candS[PQ_CREDIT ? (VR_BLOCK / 64) * VR_PQ_CANDS : 1]; // ... and candidate records (pq_credit)
   // ... and, where the credits of a round carry different weights (the general kernels), one int64 sum per candidate
@@ -478,7 +491,7 @@ trace_kernel(const TraceParams p) {
   if (tid < 96)
     wallS[tid] = p.wallTable[tid];
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < (WAVEC ? 3 : 8); ++k)
     cntS[k * VR_BLOCK + tid] = 0u;
   if (SMALL) {
     // stage the scene (the offsets are multiples of 16 bytes; vr_apply_prepare checked that it fits)
@@ -507,8 +520,16 @@ trace_kernel(const TraceParams p) {
   }
   __syncthreads();
   unsigned *const cnt = cntS + tid; // counter k of this lane: cnt[k * VR_BLOCK]
-  enum { K_TRACES = 0, K_NONGEO, K_GEO, K_BOUNDARY, K_REFL, K_TERM, K_TIER2, K_PARTICLE };
-#define VR_COUNT(k, v) atomicAdd(&cnt[(k) * VR_BLOCK], (unsigned)(v))
+  // (per-lane slots first: with WAVEC only K_BOUNDARY, K_REFL, K_TIER2 have one)
+  enum { K_BOUNDARY = 0, K_REFL, K_TIER2, K_TRACES, K_NONGEO, K_GEO, K_TERM, K_PARTICLE };
+  unsigned waveCnt[5] = {0u, 0u, 0u, 0u, 0u}; // WAVEC: K_TRACES .. K_PARTICLE, wave-uniform
+#define VR_COUNT(k, v)                                                                                                 \
+  do {                                                                                                                 \
+    if constexpr (WAVEC && (k) >= K_TRACES)                                                                            \
+      waveCnt[(k)-K_TRACES] += (unsigned)__popcll(ballot64(true));                                                      \
+    else                                                                                                               \
+      atomicAdd(&cnt[(k)*VR_BLOCK], (unsigned)(v));                                                                    \
+  } while (0)
 
   // scene data: global memory, or (MODE 4) the block's LDS copies
   const float4 *__restrict__ prims = SMALL ? reinterpret_cast<const float4 *>(sceneB + p.smallOff[1])
@@ -1146,9 +1167,13 @@ trace_kernel(const TraceParams p) {
   }
 #endif
   // (slot order of vr_types.hpp: traces, nongeo, geo, particle, boundary, reflections, terminated, tier2)
-  const unsigned vals[8] = {cnt[K_TRACES * VR_BLOCK], cnt[K_NONGEO * VR_BLOCK], cnt[K_GEO * VR_BLOCK], cnt[K_PARTICLE * VR_BLOCK],
-                            cnt[K_BOUNDARY * VR_BLOCK], cnt[K_REFL * VR_BLOCK], cnt[K_TERM * VR_BLOCK],
-                            cnt[K_TIER2 * VR_BLOCK]};
+  auto total = [&](int k) -> unsigned { // this lane's share of counter k (WAVEC: lane 0 carries the wave's)
+    if (WAVEC && k >= K_TRACES)
+      return lane == 0 ? waveCnt[k - K_TRACES] : 0u;
+    return cnt[k * VR_BLOCK];
+  };
+  const unsigned vals[8] = {total(K_TRACES), total(K_NONGEO), total(K_GEO),  total(K_PARTICLE),
+                            total(K_BOUNDARY), total(K_REFL), total(K_TERM), total(K_TIER2)};
 #undef VR_COUNT
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
