@@ -1451,13 +1451,20 @@ struct VrUserModel : ModelDiffuse {
 """
 
 
+@pytest.fixture(scope="module")
+def model_cache(tmp_path_factory):
+    """one code-object cache for the whole module: each run-time model is compiled once (about 11 s), then found"""
+    return str(tmp_path_factory.mktemp("vr_model_cache"))
+
+
 @pytest.mark.parametrize("geom", ["trench3d", "plane", "trench2d", "mesh"])
-def test_particle_model_registered_at_run_time(geom, tmp_path, monkeypatch):
+def test_particle_model_registered_at_run_time(geom, model_cache, monkeypatch):
     """OPEN registration (gpu/raygCallableConfig.hpp:7-18: the reference's GPU path registers user callables per particle):
     the SOURCE of a model is compiled at run time (hipcc --genco), loaded as a code object and traced.  Two user models
     that restate built-in ones give the built-in particles' flux bit for bit, on every kernel variant (general, flat
     scene with packet-query crediting, LDS-resident scene, triangles) — alone and inside a particle list."""
-    monkeypatch.setenv("VR_CACHE_DIR", str(tmp_path))
+    tmp_path = model_cache
+    monkeypatch.setenv("VR_CACHE_DIR", tmp_path)
 
     def tracer():
         if geom == "plane":
