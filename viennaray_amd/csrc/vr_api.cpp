@@ -229,6 +229,8 @@ struct vr_context {
   uint32_t numBins = 0;
   uint64_t rayFirstLaunch = 0, rayEndLaunch = 0;
   bool absorb = true;
+  bool recExtra = false;      // non-absorbing particle under a tilted / grid / host source: the records' side array
+  DevBuf<float> dRecExtra;
   std::vector<hipEvent_t> evK; // trace-kernel event pairs, one per batch
   std::vector<hipEvent_t> evG; // generator event pairs, one per batch
   double traceKernelSeconds = 0.0;
@@ -1078,14 +1080,19 @@ static int prepare_one(vr_context *c) {
     {
       Tri walls[8];
       host_build_walls(c->bbLo, c->bbHi, c->ts[1], c->ts[2], walls);
-      float tbl[96];
+      float tbl[100]; // 8 walls, then the source frame the tracer rebuilds compact ray records with (vr_types.hpp)
       for (int i = 0; i < 8; ++i) {
         std::memcpy(tbl + 12 * i, walls[i].v0, 12);
         std::memcpy(tbl + 12 * i + 3, walls[i].e1, 12);
         std::memcpy(tbl + 12 * i + 6, walls[i].e2, 12);
         std::memcpy(tbl + 12 * i + 9, walls[i].Ng, 12);
       }
-      VR_HIP(c, c->dWalls.ensure(96));
+      tbl[96] = c->ts[3] ? c->bbHi[c->ts[0]] : c->bbLo[c->ts[0]]; // origin[rayDir]: the source plane
+      for (int k = 0; k < 3; ++k) {
+        const int32_t axis = c->ts[k];
+        std::memcpy(&tbl[97 + k], &axis, 4);
+      }
+      VR_HIP(c, c->dWalls.ensure(100));
       VR_HIP(c, hipMemcpy(c->dWalls.p, tbl, sizeof(tbl), hipMemcpyHostToDevice));
     }
     // rayBoundary.hpp:23-25: conditions are picked by AXIS
@@ -1312,7 +1319,12 @@ static int prepare_one(vr_context *c) {
     c->numBins = nb;
     const size_t slots = (size_t)nb * binCap + cap; // bins + overflow region
     c->slotStride = slots;
-    const size_t recFloats = c->absorb ? 8 : 12; // 32 B, or 32 B + the 16-B RNG cursors
+    // 32-byte records for every particle (vr_types.hpp); a non-absorbing particle under a source whose origin plane or
+    // draw count varies (tilted, grid, host rays) adds 16 bytes per ray in a side array
+    c->recExtra = !c->absorb && (c->usePrimaryDirection || !c->gridPoints.empty() || !c->hostOrg.empty());
+    const size_t recFloats = 8;
+    if (c->recExtra)
+      VR_HIP(c, c->dRecExtra.ensure_grow((size_t)cap * 4));
     size_t slotsWant = slots, binsWant = (size_t)nb + 1;
     if (c->reserveRays > span) { // vr_reserve_rays: room for the largest apply() announced
       TraceParams q = p;
@@ -1445,6 +1457,7 @@ static int prepare_one(vr_context *c) {
   VR_HIP(c, c->dWorkQ.ensure(VR_QUEUES * VR_QUEUE_STRIDE));
   p.workCounter = c->dWorkQ.p;
   p.numQueues = VR_QUEUES;
+  p.recExtra = c->recExtra ? c->dRecExtra.p : nullptr;
   p.rngScratch = c->dScratch.p;
   p.slotRec = c->dSlotRec.p;
   p.binCount = c->dBinCount.p;
@@ -1868,6 +1881,7 @@ int vr_apply_prepare(vr_context *c) {
     lp.walkStack = c->dWalkStack.p;
     lp.rngScratch = c->dScratch.p;
     lp.workCounter = c->dWorkQ.p;
+    lp.recExtra = lp.recExtra ? c->dRecExtra.p : nullptr;
     lp.counters = c->dCounters.p + 80 * q;
     lp.fluxAcc = c->dFluxAcc.p + (size_t)c->launches[q].dataBase * lp.planeStride;
   }

@@ -145,12 +145,17 @@ __device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, 
     else
       slot = p.numBins * p.binCap + atomicAdd(&p.binCount[p.numBins], 1u); // < ovCap by construction
   }
-  // record = {A, B} (32 B) [+ the RNG cursors {s[k], s[k+156]} (16 B) when the particle keeps going]
-  float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + (size_t)(KEEP ? 3 : 2) * slot;
-  rec[0] = make_float4(o.x, o.y, o.z, d.x);
-  rec[1] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(k));
-  if (KEEP)
-    *reinterpret_cast<ulonglong2 *>(rec + 2) = make_ulonglong2(lo, hi);
+  float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + (size_t)2 * slot;
+  if (KEEP) {
+    // the compact record (vr_types.hpp) + what the plain generator's rays do not need: origin[rayDir], k, s[k]
+    rec[0] = make_float4(getc(o, p.firstDir), getc(o, p.secondDir), d.x, d.y);
+    rec[1] = make_float4(d.z, __uint_as_float(i), __uint_as_float((unsigned)(hi & 0xFFFFFFFFull)), __uint_as_float((unsigned)(hi >> 32)));
+    reinterpret_cast<float4 *>(const_cast<float *>(p.recExtra))[i] =
+        make_float4(getc(o, p.rayDir), __uint_as_float(k), __uint_as_float((unsigned)(lo & 0xFFFFFFFFull)), __uint_as_float((unsigned)(lo >> 32)));
+  } else {
+    rec[0] = make_float4(o.x, o.y, o.z, d.x);
+    rec[1] = make_float4(d.y, d.z, __uint_as_float(i), __uint_as_float(k));
+  }
   return slot;
 }
 
@@ -190,11 +195,18 @@ template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_kern
           slot = p.numBins * p.binCap + atomicAdd(&p.binCount[p.numBins], 1u); // < ovCap by construction
       }
       // record = {A, B} (32 B) [+ the RNG cursors {s[k], s[k+156]} (16 B) when the particle keeps going]
-      float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + (size_t)(KEEP ? 3 : 2) * slot;
-      rec[0] = make_float4(po.x, po.y, po.z, pd.x);
-      rec[1] = make_float4(pd.y, pd.z, __uint_as_float(pi), __uint_as_float((unsigned)NS));
-      if (KEEP)
-        *reinterpret_cast<ulonglong2 *>(rec + 2) = make_ulonglong2(plo, phi);
+      if (KEEP) {
+        // compact: the origin's two free coordinates, the direction, the index and s[k+156]; the tracer knows the source
+        // plane and the draw count and rebuilds s[k] from the seed (vr_types.hpp)
+        float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + (size_t)2 * slot;
+        rec[0] = make_float4(getc(po, p.firstDir), getc(po, p.secondDir), pd.x, pd.y);
+        rec[1] = make_float4(pd.z, __uint_as_float(pi), __uint_as_float((unsigned)(phi & 0xFFFFFFFFull)),
+                             __uint_as_float((unsigned)(phi >> 32)));
+      } else {
+        float4 *rec = reinterpret_cast<float4 *>(p.slotRec) + (size_t)2 * slot;
+        rec[0] = make_float4(po.x, po.y, po.z, pd.x);
+        rec[1] = make_float4(pd.y, pd.z, __uint_as_float(pi), __uint_as_float((unsigned)NS));
+      }
     }
     if (!cur)
       break;
@@ -461,7 +473,7 @@ trace_kernel(const TraceParams p) {
   // The absorbing kernel for flat scenes does without: its rounds are packets, and the extra
   // live registers would cost it the 8th wave per SIMD.
   constexpr bool CARRY = MODE != 1;
-  __shared__ float wallS[96];
+  __shared__ float wallS[104]; // (96 .. 101: the source frame of the compact ray records, the side array's address)
   // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
   // The general kernels count five of the eight events per WAVE (a wave-uniform register += popcount of the lanes
   // that reach the count) and keep per-lane LDS words only for the three that are added as values or passed by
@@ -488,8 +500,10 @@ trace_kernel(const TraceParams p) {
   cands.rec = candS + (PQ_CREDIT ? (tid >> 6) * VR_PQ_CANDS : 0u);
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
-  if (tid < 96)
+  if (tid < 100)
     wallS[tid] = p.wallTable[tid];
+  if (tid == 100 || tid == 101) // (read per lane at a refill: as a kernel argument the pointer would be held in SGPRs throughout)
+    wallS[tid] = __uint_as_float((unsigned)((unsigned long long)p.recExtra >> (tid == 100 ? 0 : 32)));
 #pragma unroll
   for (int k = 0; k < (WAVEC ? 3 : 8); ++k)
     cntS[k * VR_BLOCK + tid] = 0u;
@@ -695,15 +709,42 @@ trace_kernel(const TraceParams p) {
       if (slot != 0xFFFFFFFFu) {
         DIAG(8);
         const unsigned j = slot;
-        constexpr unsigned REC = ABSORB ? 2 : 3; // float4 per record
-        const float4 a = rayAB[REC * (size_t)j];
-        const float4 b = rayAB[REC * (size_t)j + 1];
-        org = mk(a.x, a.y, a.z);
-        rayDirection = mk(a.w, b.x, b.y);
+        const float4 a = rayAB[2 * (size_t)j]; // (32-byte records in both forms, vr_types.hpp)
+        const float4 b = rayAB[2 * (size_t)j + 1];
+        if (!ABSORB) {
+          // compact form.  (The source frame comes from LDS, per lane: as kernel arguments these loop-invariant scalars
+          //  were hoisted and held across the whole kernel — scalar spills in every instantiation.)
+          float srcPlane = wallS[96];
+          const int rd = __float_as_int(wallS[97]), fd = __float_as_int(wallS[98]);
+          const unsigned long long ex = ((unsigned long long)__float_as_uint(wallS[101]) << 32) | __float_as_uint(wallS[100]);
+          const unsigned seed32 = tea3((unsigned)(p.batchFirst + __float_as_uint(b.y)), p.seed);
+          constexpr unsigned NS = D == 3 ? 4u : 3u; // draws of the plain generator (gen_kernel)
+          unsigned k = NS;
+          u64 lo;
+          if (ex) { // a source with its own origin plane / draw count: the side array has them and s[k]
+            const float4 e = reinterpret_cast<const float4 *>(ex)[__float_as_uint(b.y)];
+            srcPlane = e.x;
+            k = __float_as_uint(e.y);
+            lo = ((u64)__float_as_uint(e.w) << 32) | __float_as_uint(e.z);
+          } else {
+            lo = seed32; // s[NS]: NS steps of the seeding recurrence
+#pragma unroll
+            for (unsigned st = 1; st <= NS; ++st)
+              lo = mt_step(lo, st);
+          }
+          org.x = rd == 0 ? srcPlane : (fd == 0 ? a.x : a.y);
+          org.y = rd == 1 ? srcPlane : (fd == 1 ? a.x : a.y);
+          org.z = rd == 2 ? srcPlane : (fd == 2 ? a.x : a.y);
+          rayDirection = mk(a.z, a.w, b.x);
+          rng_resume(rng, seed32, k, lo, ((u64)__float_as_uint(b.w) << 32) | __float_as_uint(b.z));
+        } else {
+          org = mk(a.x, a.y, a.z);
+          rayDirection = mk(a.w, b.x, b.y);
+        }
         dir = project_dir<D>(rayDirection); // what Embree sees (rayUtil.hpp:204-227)
         rayWeight = 1.f;                    // Source::getInitialRayWeight
         if (!ABSORB && p.hostWeights) {     // (a host-callback source with weights of its own never runs an absorbing kernel)
-          rayWeight = p.hostWeights[p.batchFirst + __float_as_uint(b.z)];
+          rayWeight = p.hostWeights[p.batchFirst + __float_as_uint(b.y)];
           initWeightBits = __float_as_uint(rayWeight);
         }
         numReflections = 0;
@@ -711,11 +752,6 @@ trace_kernel(const TraceParams p) {
         hitFromBack = false;
         active = true;
         start = true;
-        if (!ABSORB) {
-          const unsigned idxOff = __float_as_uint(b.z);
-          const ulonglong2 cur = *reinterpret_cast<const ulonglong2 *>(rayAB + REC * (size_t)j + 2);
-          rng_resume(rng, tea3((unsigned)(p.batchFirst + idxOff), p.seed), __float_as_uint(b.w), cur.x, cur.y);
-        }
       }
     }
     if (!ballot64(active))

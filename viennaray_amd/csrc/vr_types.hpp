@@ -31,8 +31,14 @@ struct Tri {       // boundary wall triangle, Embree's precomputed form
 // Ray stream record (HBM-resident, sorted by source-plane cell before tracing):
 //   32 B: A = {org.x, org.y, org.z, dir.x}   B = {dir.y, dir.z, bits(idx - batchFirst), bits(k)}
 //   k = number of engine outputs the source sampling consumed
-//   +16 B (only for particles that keep going after a hit): C = {s[k], s[k+156]}, the two
-//   cursors of the streaming mt19937_64 (vr_device.hpp, struct Rng)
+//   (the form the absorbing kernels read: nothing after the first hit is observable, no engine state needed)
+// Particles that keep going after a hit need the engine's streaming cursors {s[k], s[k+156]} (vr_device.hpp, struct
+// Rng) as well — in 32 bytes too (round 3; it had been 48, and a 48-byte record straddles two 64-byte write bursts
+// every other time: 96 bytes of fabric writes per ray against 64):
+//   A = {org[firstDir], org[secondDir], dir.x, dir.y}   B = {dir.z, bits(idx - batchFirst), s[k+156] lo, hi}
+//   org[rayDir] is the source plane, k the generator's fixed draw count and s[k] = k chain steps from the seed: the
+//   tracer rebuilds them.  The sources for which that does not hold (tilted primary direction: k varies; SourceGrid and
+//   host rays: any origin) add 16 bytes per ray in a side array, TraceParams::recExtra.
 constexpr unsigned VR_BIN_CAP = 128; // record slots per sort bin (4 KB of 32-byte records: the generator's scattered stores
                                     // and the bin cursors do better with bins a page apart than with 64 slots)
 constexpr int VR_BLOCK = 256;
@@ -133,6 +139,8 @@ struct TraceParams {
   // ---- round 3 (appended: the kernels' scalar loads of the fields above keep their offsets and alignment — the
   //      absorbing kernels sit at a fragile optimum of the register allocator) ----
   uint32_t numQueues;              // 1, or 8: one queue of sort bins per XCD (vr_trace.hip, refill)
+  const float *recExtra;           // [batchCount] x {origin[rayDir], bits(k), s[k] lo, hi} for the sources whose origin plane or
+                                   // draw count varies (tilted, grid, host rays); nullptr for the plain SourceRandom generator
   const float *hostWeights;        // Source::getInitialRayWeight(idx) of a host-callback source (nullptr: 1, raySource.hpp:18)
   float particleParams[8];         // vr_particle::params: the model's own parameters (ModelCtx::params)
   // Trace::setGlobalData (rayTrace.hpp:137-145): read-only vectors indexed by the ORIGINAL primitive id, and scalars
