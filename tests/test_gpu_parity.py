@@ -959,6 +959,78 @@ def test_random_scenes_match_oracle(seed):
     assert np.allclose(a[ok], b[ok], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_random_particle_lists_match_oracle(seed):
+    """Randomised differential test of the registry and of particle lists: a random scene (as above, incl. tilted
+    sources: the records' side array), random global data, material ids, and a list of 1 - 4 random particles —
+    built-in, coned-cosine, two-label, coverage-dependent sticking, with and without per-material sticking — traced
+    in ONE apply against one oracle run per particle with the same run number: every counter and every data label."""
+    c = _random_case(7000 + seed)
+    rng = np.random.default_rng(9000 + seed)
+    n = len(c["pts"])
+    mats = rng.integers(0, 3, size=n).astype(np.int32)
+    cov = rng.uniform(0, 1, size=(2, n)).astype(np.float32)
+    t = vr.TraceDisk(c["D"])
+    t.setGeometry(c["pts"], c["nrm"], c["gd"], c["radius"])
+    t.setBoundaryConditions(c["bcs"])
+    t.setSourceDirection(c["direction"])
+    t.setMaterialIds(mats)
+    t.setGlobalData([cov[0], cov[1]])
+    t.setNumberOfRaysPerPoint(c["rays"])
+    t.setRngSeed(c["seed"])
+    t.setMaxReflections(c["max_refl"])
+    t.setMaxBoundaryHits(c["max_bh"])
+    if c["primary"] is not None:
+        t.setPrimaryDirection(c["primary"])
+    plist = []
+    for _ in range(int(rng.integers(1, 5))):
+        kind = int(rng.integers(0, 5))
+        s = float(rng.choice([1.0, 0.6, 0.25, 0.05]))
+        ms = {int(m): float(rng.choice([1.0, 0.5, 0.1])) for m in rng.choice(3, size=int(rng.integers(0, 3)), replace=False)}
+        power = float(rng.choice([1.0, 6.0]))
+        if kind == 0:
+            plist.append((vr.DiffuseParticle(s, "a", ms), po.DIFFUSE, s, 1.0, 0.0, ms))
+        elif kind == 1:
+            plist.append((vr.SpecularParticle(s, power, "a", ms), po.SPECULAR, s, power, 0.0, ms))
+        elif kind == 2:
+            cone = float(rng.choice([0.0, 0.4, 1.1]))
+            plist.append((vr.ConedCosineParticle(s, power, cone, "a", ms), po.CONED_COSINE, s, power, cone, ms))
+        elif kind == 3:
+            plist.append((vr.DiffuseCosineParticle(s, "a", "b", ms), po.DIFFUSE_COSINE, s, 1.0, 0.0, ms))
+        else:
+            v = int(rng.integers(0, 2))
+            plist.append((vr.CoverageStickingParticle(s, "a", v, ms), po.COVERAGE_STICKING, s, 1.0, float(v), ms))
+    t.setParticleTypes([q[0] for q in plist])
+    t.apply()
+    ld = t.getLocalData()
+    plane = 0
+    for q, (_, okind, s, power, cone, ms) in enumerate(plist):
+        o = po.Oracle()
+        o.set_disks(c["pts"], c["nrm"], c["gd"], c["D"], radius=c["radius"])
+        o.set_boundary_conditions([int(b) for b in c["bcs"]])
+        o.set_source_direction(int(c["direction"]))
+        o.set_material_ids(mats)
+        o.set_global_data(0, cov[0])
+        o.set_global_data(1, cov[1])
+        o.set_particle_ex(okind, s, power, cone, -1.0)
+        if ms:
+            o.set_material_sticking(ms)
+        o.set_num_rays_per_point(c["rays"])
+        o.set_rng_seed(c["seed"])
+        o.set_max_reflections(c["max_refl"])
+        o.set_max_boundary_hits(c["max_bh"])
+        if c["primary"] is not None:
+            o.set_primary_direction(c["primary"])
+        o.set_lazy_rng(True)
+        o.apply(4)
+        pi, oi = t.getParticleTraceInfo(q), o.info()
+        assert {k: int(getattr(pi, k)) for k in INFO_KEYS} == {k: oi[k] for k in INFO_KEYS}, (q, okind)
+        for l in range(o.num_data()):
+            assert l2_rel(ld.getVectorData(plane), o.flux_data(l)) <= 5e-6, (q, okind, l)
+            plane += 1
+    assert plane == t.numData()
+
+
 @pytest.mark.parametrize("seed", range(16))
 def test_random_triangle_surfaces_match_oracle(seed):
     """random rough height fields as triangle meshes, random walls / particle / limits"""

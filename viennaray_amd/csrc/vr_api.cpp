@@ -544,9 +544,12 @@ int vr_register_particle_model(vr_context *c, const char *name, const char *sour
     }
     const char *hipcc = std::getenv("VR_HIPCC");
     const std::string tmp = base + ".tmp" + std::to_string((int)getpid());
-    const std::string cmd = std::string(hipcc ? hipcc : "/opt/rocm/bin/hipcc") +
+    auto quoted = [](const std::string &path) { return "'" + path + "'"; }; // (paths with blanks; a quote in a path is refused below)
+    if ((cache + csrc).find('\'') != std::string::npos)
+      return fail(c, VR_E_INVALID, "vr_register_particle_model: the cache / source directory must not contain a quote character");
+    const std::string cmd = quoted(hipcc ? hipcc : "/opt/rocm/bin/hipcc") +
                             " --genco --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -I" +
-                            csrc + " " + base + ".hip -o " + tmp + " > " + base + ".log 2>&1";
+                            quoted(csrc) + " " + quoted(base + ".hip") + " -o " + quoted(tmp) + " > " + quoted(base + ".log") + " 2>&1";
     const int rc = std::system(cmd.c_str());
     if (rc != 0) {
       std::string all, log;
