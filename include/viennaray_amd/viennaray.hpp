@@ -35,6 +35,7 @@
 #include <cmath>
 #include <cstdint>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <limits>
 #include <memory>
@@ -392,10 +393,13 @@ public:
 // pass a DataLog around keep compiling.
 template <class NumericType> struct DataLog {
   std::vector<std::vector<NumericType>> data;
+  // element-wise sum of two logs (the shorter extent of each row counts)
   void merge(DataLog<NumericType> &pOther) {
-    for (std::size_t i = 0; i < data.size() && i < pOther.data.size(); i++)
-      for (std::size_t j = 0; j < data[i].size() && j < pOther.data[i].size(); j++)
-        data[i][j] += pOther.data[i][j];
+    const std::size_t rows = std::min(data.size(), pOther.data.size());
+    for (std::size_t r = 0; r < rows; ++r) {
+      const std::size_t cols = std::min(data[r].size(), pOther.data[r].size());
+      std::transform(data[r].begin(), data[r].begin() + cols, pOther.data[r].begin(), data[r].begin(), std::plus<NumericType>());
+    }
   }
 };
 
@@ -403,21 +407,23 @@ template <class NumericType> struct DataLog {
 
 namespace rayInternal {
 using namespace viennacore;
-// rayUtil.hpp:266-283
+// rayUtil.hpp:266-283: Marsaglia's rejection method — a point of the unit disc (pairs from U(-1,1) until inside)
+// lifted onto the sphere.  The reference's arithmetic: the squared radius and the lift factor in double, the
+// coordinates narrowed back to NumericType.
 template <typename NumericType> viennacore::Vec3D<NumericType> pickRandomPointOnUnitSphere(viennacore::RNG &rngState) {
-  static thread_local std::uniform_real_distribution<NumericType> uniDist(NumericType(-1), NumericType(1));
-  NumericType x, y, z;
-  double x2py2;
-  do {
-    x = uniDist(rngState);
-    y = uniDist(rngState);
-    x2py2 = x * x + y * y;
-  } while (x2py2 >= 1.);
-  double tmp = 2. * std::sqrt(1. - x2py2);
-  x *= tmp;
-  y *= tmp;
-  z = 1. - 2 * x2py2;
-  return viennacore::Vec3D<NumericType>{x, y, z};
+  static thread_local std::uniform_real_distribution<NumericType> symmetric(NumericType(-1), NumericType(1));
+  NumericType u = 0, v = 0;
+  double radiusSq = 2.;
+  while (radiusSq >= 1.) {
+    u = symmetric(rngState);
+    v = symmetric(rngState);
+    radiusSq = u * u + v * v;
+  }
+  const double lift = 2. * std::sqrt(1. - radiusSq);
+  u *= lift;
+  v *= lift;
+  const NumericType w = 1. - 2 * radiusSq;
+  return viennacore::Vec3D<NumericType>{u, v, w};
 }
 // rayUtil.hpp:145-202: {rayDir, firstDir, secondDir, minMax, posNeg}
 inline std::array<int, 5> getTraceSettings(unsigned sourceDir) {
@@ -452,40 +458,44 @@ void adjustBoundingBox(std::array<viennacore::Vec3D<NumericType>, 2> &bdBox, Dir
 template <class Direction> std::array<int, 5> getTraceSettings(Direction d) { return getTraceSettings((unsigned)d); }
 
 // rayUtil.hpp:564-611
+// rayUtil.hpp:564-611: a regular lattice of ray origins on the source face of the bounding box, about `pNumPoints`
+// of them, in the proportion of the face's sides; margins of 1e-4 keep the origins off the walls.  The lattice is
+// walked by repeated addition like the reference's (the float sums ARE the coordinates: tests/createSourceGrid).
 template <typename NumericType, int D>
 [[nodiscard]] std::vector<viennacore::Vec3D<NumericType>>
 createSourceGrid(const std::array<viennacore::Vec3D<NumericType>, 2> &pBdBox, const size_t pNumPoints,
                  const NumericType pGridDelta, const std::array<int, 5> &pTraceSettings) {
-  std::vector<viennacore::Vec3D<NumericType>> sourceGrid;
-  sourceGrid.reserve(pNumPoints);
-  constexpr double eps = 1e-4;
-  auto rayDir = pTraceSettings[0];
-  auto firstDir = pTraceSettings[1];
-  auto secondDir = pTraceSettings[2];
-  auto minMax = pTraceSettings[3];
-  auto len1 = pBdBox[1][firstDir] - pBdBox[0][firstDir];
-  auto len2 = pBdBox[1][secondDir] - pBdBox[0][secondDir];
-  auto numPointsInFirstDir = static_cast<size_t>(round(len1 / pGridDelta));
-  auto numPointsInSecondDir = static_cast<size_t>(round(len2 / pGridDelta));
-  const unsigned long ratio = numPointsInFirstDir / numPointsInSecondDir;
-  numPointsInFirstDir = static_cast<size_t>(std::sqrt(pNumPoints * ratio));
-  numPointsInSecondDir = static_cast<size_t>(std::sqrt(pNumPoints / ratio));
-  auto firstGridDelta = (len1 - 2 * eps) / static_cast<NumericType>(numPointsInFirstDir - 1);
-  auto secondGridDelta = (len2 - 2 * eps) / static_cast<NumericType>(numPointsInSecondDir - 1);
-  viennacore::Vec3D<NumericType> point;
-  point[rayDir] = pBdBox[minMax][rayDir];
-  for (auto uu = pBdBox[0][secondDir] + eps; uu <= pBdBox[1][secondDir] - eps; uu += secondGridDelta) {
-    if constexpr (D == 2)
-      point[secondDir] = 0.;
-    else
-      point[secondDir] = uu;
-    for (auto vv = pBdBox[0][firstDir] + eps; vv <= pBdBox[1][firstDir] - eps; vv += firstGridDelta) {
-      point[firstDir] = vv;
-      sourceGrid.push_back(point);
+  const int axisRay = pTraceSettings[0], axisA = pTraceSettings[1], axisB = pTraceSettings[2];
+  const int sourceSide = pTraceSettings[3];
+  constexpr double margin = 1e-4;
+  const auto sideA = pBdBox[1][axisA] - pBdBox[0][axisA];
+  const auto sideB = pBdBox[1][axisB] - pBdBox[0][axisB];
+  // lattice counts: first from the grid spacing (only their integer ratio survives), then from the requested total
+  size_t countA = static_cast<size_t>(round(sideA / pGridDelta));
+  size_t countB = static_cast<size_t>(round(sideB / pGridDelta));
+  const unsigned long aspect = countA / countB;
+  countA = static_cast<size_t>(std::sqrt(pNumPoints * aspect));
+  countB = static_cast<size_t>(std::sqrt(pNumPoints / aspect));
+  const auto stepA = (sideA - 2 * margin) / static_cast<NumericType>(countA - 1);
+  const auto stepB = (sideB - 2 * margin) / static_cast<NumericType>(countB - 1);
+
+  std::vector<viennacore::Vec3D<NumericType>> lattice;
+  lattice.reserve(pNumPoints);
+  viennacore::Vec3D<NumericType> origin;
+  origin[axisRay] = pBdBox[sourceSide][axisRay];
+  auto b = pBdBox[0][axisB] + margin;
+  while (b <= pBdBox[1][axisB] - margin) {
+    origin[axisB] = D == 2 ? decltype(b)(0) : b;
+    auto a = pBdBox[0][axisA] + margin;
+    while (a <= pBdBox[1][axisA] - margin) {
+      origin[axisA] = a;
+      lattice.push_back(origin);
+      a += stepA;
     }
+    b += stepB;
   }
-  sourceGrid.shrink_to_fit();
-  return sourceGrid;
+  lattice.shrink_to_fit();
+  return lattice;
 }
 } // namespace rayInternal
 
@@ -498,17 +508,16 @@ template <typename NumericType, int D = 3>
   auto dirOldInv = Inv(rayDir);
   return NumericType(2 * DotProduct(geomNormal, dirOldInv)) * geomNormal - dirOldInv;
 }
+// rayReflection.hpp:31-50: cosine-distributed about the normal = a uniform point of the unit sphere pushed along the
+// normal and renormalised (2-D: the z component is dropped before the renormalisation)
 template <typename NumericType, int D>
 [[nodiscard]] Vec3D<NumericType> ReflectionDiffuse(const Vec3D<NumericType> &geomNormal, RNG &rngState) {
-  auto randomDirection = rayInternal::pickRandomPointOnUnitSphere<NumericType>(rngState);
-  randomDirection[0] += geomNormal[0];
-  randomDirection[1] += geomNormal[1];
-  if constexpr (D == 3)
-    randomDirection[2] += geomNormal[2];
-  else
-    randomDirection[2] = 0;
-  Normalize(randomDirection);
-  return randomDirection;
+  Vec3D<NumericType> lobe = rayInternal::pickRandomPointOnUnitSphere<NumericType>(rngState);
+  for (int axis = 0; axis < 2; ++axis)
+    lobe[axis] += geomNormal[axis];
+  lobe[2] = D == 3 ? NumericType(lobe[2] + geomNormal[2]) : NumericType(0);
+  Normalize(lobe);
+  return lobe;
 }
 // ReflectionConedCosine (rayReflection.hpp:52-120) assembled from two pieces of this library's own: the frame
 // around the mirror direction and the accept-reject draw of the lobe's polar angle.  The arithmetic (types,
@@ -1339,20 +1348,28 @@ void readMeshFromFile(const std::string &fileName, NumericType &gridDelta, std::
   }
 }
 
+// rayUtil.hpp:340-351: a flat point cloud in the plane spanned by direction[0] x direction[1] at coordinate 0 of
+// direction[2], from -extent to +extent in steps of gridDelta (coordinates by repeated addition, like the reference's
+// loops: the float sums are the coordinates), normals along +direction[2]
 template <typename NumericType>
 void createPlaneGrid(const NumericType gridDelta, const NumericType extent, const std::array<int, 3> direction,
                      std::vector<Vec3D<NumericType>> &points, std::vector<Vec3D<NumericType>> &normals) {
-  Vec3D<NumericType> point{-extent, -extent, -extent}, normal{0, 0, 0};
-  point[direction[2]] = 0;
-  normal[direction[2]] = 1;
+  const int outer = direction[0], inner = direction[1], up = direction[2];
+  Vec3D<NumericType> unitNormal{0, 0, 0};
+  unitNormal[up] = 1;
+  Vec3D<NumericType> cursor{-extent, -extent, -extent};
+  cursor[up] = 0;
   points.clear();
   normals.clear();
-  for (; point[direction[0]] <= extent; point[direction[0]] += gridDelta) {
-    for (point[direction[1]] = -extent; point[direction[1]] <= extent; point[direction[1]] += gridDelta) {
-      points.push_back(point);
-      normals.push_back(normal);
+  while (cursor[outer] <= extent) {
+    cursor[inner] = -extent;
+    while (cursor[inner] <= extent) {
+      points.push_back(cursor);
+      cursor[inner] += gridDelta;
     }
+    cursor[outer] += gridDelta;
   }
+  normals.assign(points.size(), unitNormal);
 }
 
 template <typename NumericType, int D = 3, typename FluxType = NumericType>

@@ -43,7 +43,7 @@ public:
     return {origin, direction};
   }
   size_t getNumPoints() const override { return n_; }
-  NumericType getSourceArea() const override { return 1; }
+  NumericType getSourceArea() const override { return NumericType(1); }
 };
 
 // a user particle that exists only as host virtuals
@@ -122,49 +122,49 @@ static void api_walk(TraceDisk<float, 3> &tracer, const std::vector<Vec3D<float>
 }
 
 int main() {
-  constexpr int D = 3;
-  using NumericType = float;
-  const NumericType extent = 5, gridDelta = 0.5;
-  std::vector<VectorType<NumericType, D>> points, normals;
+  constexpr int Dim = 3;
+  using Real = float;
+  const Real extent = 5, gridDelta = 0.5;
+  std::vector<VectorType<Real, Dim>> points, normals;
   rayInternal::createPlaneGrid(gridDelta, extent, {0, 1, 2}, points, normals);
   VC_TEST_ASSERT(points.size() == 441);
-  TracingData<NumericType> globalData; // (declared before the tracer that borrows it)
-  TraceDisk<NumericType, D> rayTracer;
-  api_walk(rayTracer, points, normals, gridDelta, globalData);
+  TracingData<Real> globalData; // (declared before the tracer that borrows it)
+  TraceDisk<Real, Dim> tracer;
+  api_walk(tracer, points, normals, gridDelta, globalData);
 
   { // host-callback source: every ray comes straight down at y = 0.3 -> only the disks under that line
-    rayTracer.setRngSeed(7);
-    rayTracer.setSource(std::make_shared<BeamSource<NumericType>>(1000));
-    rayTracer.setNumberOfRaysPerPoint(3);
-    rayTracer.apply();
-    auto i2 = rayTracer.getRayTraceInfo();
+    tracer.setRngSeed(7);
+    tracer.setSource(std::make_shared<BeamSource<Real>>(1000));
+    tracer.setNumberOfRaysPerPoint(3);
+    tracer.apply();
+    auto i2 = tracer.getRayTraceInfo();
     VC_TEST_ASSERT(!i2.error && i2.numRays == 3000 && i2.geometryHits == 3000);
-    auto f2 = rayTracer.getLocalData().getVectorData("hitFlux");
+    auto f2 = tracer.getLocalData().getVectorData("hitFlux");
     double inside = 0, outside = 0;
     for (size_t k = 0; k < points.size(); ++k)
       (std::fabs(points[k][1] - 0.3f) < 0.5f && std::fabs(points[k][0]) < 1.5f ? inside : outside) += f2[k];
     VC_TEST_ASSERT(inside > 0 && outside == 0);
     std::printf("host source: %g credited under the beam line, %g elsewhere\n", inside, outside);
-    rayTracer.resetSource();
+    tracer.resetSource();
   }
   { // SourceGrid through the reference's own helper chain
-    std::array<Vec3D<NumericType>, 2> bdBox{Vec3D<NumericType>{-extent, -extent, 0}, Vec3D<NumericType>{extent, extent, 0}};
+    std::array<Vec3D<Real>, 2> bdBox{Vec3D<Real>{-extent, -extent, 0}, Vec3D<Real>{extent, extent, 0}};
     auto ts = rayInternal::getTraceSettings(TraceDirection::POS_Z);
-    rayInternal::adjustBoundingBox<NumericType, D>(bdBox, TraceDirection::POS_Z, gridDelta);
-    auto grid = rayInternal::createSourceGrid<NumericType, D>(bdBox, points.size(), gridDelta, ts);
-    auto src = std::make_shared<SourceGrid<NumericType, D>>(bdBox, grid, NumericType(1), ts);
-    rayTracer.setSource(src);
-    rayTracer.setNumberOfRaysPerPoint(10);
-    rayTracer.apply();
-    auto i3 = rayTracer.getRayTraceInfo();
+    rayInternal::adjustBoundingBox<Real, Dim>(bdBox, TraceDirection::POS_Z, gridDelta);
+    auto grid = rayInternal::createSourceGrid<Real, Dim>(bdBox, points.size(), gridDelta, ts);
+    auto src = std::make_shared<SourceGrid<Real, Dim>>(bdBox, grid, Real(1), ts);
+    tracer.setSource(src);
+    tracer.setNumberOfRaysPerPoint(10);
+    tracer.apply();
+    auto i3 = tracer.getRayTraceInfo();
     VC_TEST_ASSERT(!i3.error && i3.numRays == grid.size() * 10);
     std::printf("source grid: %zu points, numRays %zu\n", grid.size(), i3.numRays);
-    rayTracer.resetSource();
+    tracer.resetSource();
   }
   { // plug-in particle with two data labels
-    rayTracer.setParticleType(std::make_unique<DiffuseCosineParticle<NumericType, D>>(NumericType(0.5), "flux", "cosFlux"));
-    rayTracer.apply();
-    auto &ld = rayTracer.getLocalData();
+    tracer.setParticleType(std::make_unique<DiffuseCosineParticle<Real, Dim>>(Real(0.5), "flux", "cosFlux"));
+    tracer.apply();
+    auto &ld = tracer.getLocalData();
     VC_TEST_ASSERT(ld.getVectorDataIndex("cosFlux") == 1);
     double a = 0, b = 0;
     for (auto v : ld.getVectorData("flux"))
@@ -175,31 +175,31 @@ int main() {
     std::printf("two labels: sum flux %g, sum cosFlux %g\n", a, b);
   }
   { // coned-cosine plug-in
-    rayTracer.setParticleType(std::make_unique<ConedCosineParticle<NumericType, D>>(NumericType(0.3), NumericType(2),
-                                                                                   NumericType(0.5), "flux"));
-    rayTracer.apply();
-    VC_TEST_ASSERT(!rayTracer.getRayTraceInfo().error && rayTracer.getRayTraceInfo().reflections > 0);
+    tracer.setParticleType(std::make_unique<ConedCosineParticle<Real, Dim>>(Real(0.3), Real(2),
+                                                                                   Real(0.5), "flux"));
+    tracer.apply();
+    VC_TEST_ASSERT(!tracer.getRayTraceInfo().error && tracer.getRayTraceInfo().reflections > 0);
   }
   { // global data on the device.  A floor with a wall on it, so that reflected rays meet the surface again: coverage 1
     // everywhere = sticking 0 = a ray keeps its whole weight for the next hit; coverage 0 = plain sticking 0.5
-    std::vector<VectorType<NumericType, D>> cornerPts = points, cornerNrm = normals;
-    for (NumericType y = -extent; y <= extent; y += gridDelta)
-      for (NumericType z = gridDelta; z <= NumericType(3); z += gridDelta) {
-        cornerPts.push_back({NumericType(-2), y, z});
-        cornerNrm.push_back({NumericType(1), NumericType(0), NumericType(0)});
+    std::vector<VectorType<Real, Dim>> cornerPts = points, cornerNrm = normals;
+    for (Real y = -extent; y <= extent; y += gridDelta)
+      for (Real z = gridDelta; z <= Real(3); z += gridDelta) {
+        cornerPts.push_back({Real(-2), y, z});
+        cornerNrm.push_back({Real(1), Real(0), Real(0)});
       }
-    TraceDisk<NumericType, D> corner;
-    TracingData<NumericType> coverage; // (outlives the applies below: the tracer keeps the pointer)
+    TraceDisk<Real, Dim> corner;
+    TracingData<Real> coverage; // (outlives the applies below: the tracer keeps the pointer)
     coverage.setNumberOfVectorData(1);
-    coverage.setVectorData(0, cornerPts.size(), NumericType(1), "coverage");
+    coverage.setVectorData(0, cornerPts.size(), Real(1), "coverage");
     corner.setGeometry(cornerPts, cornerNrm, gridDelta);
-    BoundaryCondition mirrors[D] = {BoundaryCondition::REFLECTIVE_BOUNDARY, BoundaryCondition::REFLECTIVE_BOUNDARY,
+    BoundaryCondition mirrors[Dim] = {BoundaryCondition::REFLECTIVE_BOUNDARY, BoundaryCondition::REFLECTIVE_BOUNDARY,
                                     BoundaryCondition::REFLECTIVE_BOUNDARY};
     corner.setBoundaryConditions(mirrors);
     corner.setNumberOfRaysPerPoint(20);
     corner.setRngSeed(3);
     corner.setGlobalData(coverage);
-    corner.setParticleType(std::make_unique<CoverageStickingParticle<NumericType, D>>(NumericType(0.5), "flux", 0));
+    corner.setParticleType(std::make_unique<CoverageStickingParticle<Real, Dim>>(Real(0.5), "flux", 0));
     auto total = [&] {
       corner.setRngSeed(3); // (the seed is rngSeed + runNumber, and apply() advances runNumber)
       corner.apply();
@@ -211,20 +211,20 @@ int main() {
     const double covered = total();
     const auto infoCovered = corner.getRayTraceInfo();
     for (auto &v : coverage.getVectorData(0))
-      v = NumericType(0);
+      v = Real(0);
     const double bare = total(); // (the borrowed data changed between the applies: it is uploaded again)
     VC_TEST_ASSERT(!infoCovered.error && !corner.getRayTraceInfo().error && infoCovered.reflections > infoCovered.numRays / 2);
     VC_TEST_ASSERT(covered > bare * 1.02);
     std::printf("coverage sticking: %g credited fully covered, %g bare\n", covered, bare);
   }
   { // a particle list in one apply: the labels of all particles, in order
-    std::vector<std::unique_ptr<AbstractParticle<NumericType>>> list;
-    list.push_back(std::make_unique<DiffuseParticle<NumericType, D>>(NumericType(0.2), "neutral"));
-    list.push_back(std::make_unique<SpecularParticle<NumericType, D>>(NumericType(0.9), NumericType(20), "ion"));
-    rayTracer.setParticleTypes(list);
-    rayTracer.apply();
-    auto &ld = rayTracer.getLocalData();
-    VC_TEST_ASSERT(!rayTracer.getRayTraceInfo().error && ld.getVectorDataIndex("neutral") == 0 && ld.getVectorDataIndex("ion") == 1);
+    std::vector<std::unique_ptr<AbstractParticle<Real>>> list;
+    list.push_back(std::make_unique<DiffuseParticle<Real, Dim>>(Real(0.2), "neutral"));
+    list.push_back(std::make_unique<SpecularParticle<Real, Dim>>(Real(0.9), Real(20), "ion"));
+    tracer.setParticleTypes(list);
+    tracer.apply();
+    auto &ld = tracer.getLocalData();
+    VC_TEST_ASSERT(!tracer.getRayTraceInfo().error && ld.getVectorDataIndex("neutral") == 0 && ld.getVectorDataIndex("ion") == 1);
     double a = 0, b = 0;
     for (auto v : ld.getVectorData("neutral"))
       a += v;
@@ -241,16 +241,16 @@ int main() {
                       "    credit(0, w * m.params[0]);\n"
                       "  }\n"
                       "};\n";
-    const int kind = rayTracer.registerParticleModel("scaled", src, 1);
-    VC_TEST_ASSERT(kind >= VR_PARTICLE_USER_BASE && !rayTracer.getRayTraceInfo().error);
-    rayTracer.setNumberOfRaysPerPoint(200); // (the two applies below use different seeds: enough rays for a 1 % comparison)
-    rayTracer.setParticleType(std::make_unique<UserModelParticle<NumericType, D>>(kind, NumericType(0.5), std::vector<std::string>{"scaled"},
-                                                                                 NumericType(1), std::vector<float>{2.5f}));
-    rayTracer.apply();
-    const std::vector<NumericType> scaled = rayTracer.getLocalData().getVectorData("scaled");
-    rayTracer.setParticleType(std::make_unique<DiffuseParticle<NumericType, D>>(NumericType(0.5), "plain"));
-    rayTracer.apply();
-    const auto &plain = rayTracer.getLocalData().getVectorData("plain");
+    const int kind = tracer.registerParticleModel("scaled", src, 1);
+    VC_TEST_ASSERT(kind >= VR_PARTICLE_USER_BASE && !tracer.getRayTraceInfo().error);
+    tracer.setNumberOfRaysPerPoint(200); // (the two applies below use different seeds: enough rays for a 1 % comparison)
+    tracer.setParticleType(std::make_unique<UserModelParticle<Real, Dim>>(kind, Real(0.5), std::vector<std::string>{"scaled"},
+                                                                                 Real(1), std::vector<float>{2.5f}));
+    tracer.apply();
+    const std::vector<Real> scaled = tracer.getLocalData().getVectorData("scaled");
+    tracer.setParticleType(std::make_unique<DiffuseParticle<Real, Dim>>(Real(0.5), "plain"));
+    tracer.apply();
+    const auto &plain = tracer.getLocalData().getVectorData("plain");
     double a = 0, b = 0;
     for (size_t k = 0; k < plain.size(); ++k) {
       a += scaled[k];
@@ -258,12 +258,12 @@ int main() {
     }
     VC_TEST_ASSERT(b > 0 && std::fabs(a / b - 2.5) < 0.05);
     std::printf("run-time model: sum %g = %.3f x the plain particle's %g\n", a, a / b, b);
-    rayTracer.setNumberOfRaysPerPoint(10);
+    tracer.setNumberOfRaysPerPoint(10);
   }
   { // a host-only user particle is refused, loudly
-    rayTracer.setParticleType(std::make_unique<HostOnlyParticle<NumericType>>());
-    rayTracer.apply();
-    VC_TEST_ASSERT(rayTracer.getRayTraceInfo().error);
+    tracer.setParticleType(std::make_unique<HostOnlyParticle<Real>>());
+    tracer.apply();
+    VC_TEST_ASSERT(tracer.getRayTraceInfo().error);
   }
   std::printf("facade interface ok\n");
   return 0;

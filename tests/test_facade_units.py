@@ -94,7 +94,7 @@ def test_cpp_facade_reflection_and_source_grid_bit_equal_to_oracle(tmp_path):
     rd[:50] = -nrm[:50]                          # normal incidence; mirror direction at the frame's pole:
     nrm[50:60] = [0, 0, -1]
     rd[50:60] = [0, 0, 1]
-    cones = np.array([0.3, 1.2, 0.05, 1.5], dtype=np.float32)
+    cones = np.array([0.3, 1.2, 0.05, 1.5, 2.0, 0.0], dtype=np.float32)   # (>= pi/2: ReflectionDiffuse; 0: ReflectionSpecular)
     with open(tmp_path / "in.bin", "wb") as fh:
         fh.write(np.array([n, cones.size], dtype=np.int32).tobytes() + cones.tobytes() + rd.tobytes() + nrm.tobytes())
     out = subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
