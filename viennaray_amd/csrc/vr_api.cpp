@@ -229,6 +229,7 @@ struct vr_context {
   uint32_t numBins = 0;
   uint64_t rayFirstLaunch = 0, rayEndLaunch = 0;
   bool absorb = true;
+  float frameHost[24] = {0};  // the scalar frame behind the wall table (staging buffer of its upload)
   bool recExtra = false;      // non-absorbing particle under a tilted / grid / host source: the records' side array
   DevBuf<float> dRecExtra;
   std::vector<hipEvent_t> evK; // trace-kernel event pairs, one per batch
@@ -1083,19 +1084,14 @@ static int prepare_one(vr_context *c) {
     {
       Tri walls[8];
       host_build_walls(c->bbLo, c->bbHi, c->ts[1], c->ts[2], walls);
-      float tbl[100]; // 8 walls, then the source frame the tracer rebuilds compact ray records with (vr_types.hpp)
+      float tbl[96];
       for (int i = 0; i < 8; ++i) {
         std::memcpy(tbl + 12 * i, walls[i].v0, 12);
         std::memcpy(tbl + 12 * i + 3, walls[i].e1, 12);
         std::memcpy(tbl + 12 * i + 6, walls[i].e2, 12);
         std::memcpy(tbl + 12 * i + 9, walls[i].Ng, 12);
       }
-      tbl[96] = c->ts[3] ? c->bbHi[c->ts[0]] : c->bbLo[c->ts[0]]; // origin[rayDir]: the source plane
-      for (int k = 0; k < 3; ++k) {
-        const int32_t axis = c->ts[k];
-        std::memcpy(&tbl[97 + k], &axis, 4);
-      }
-      VR_HIP(c, c->dWalls.ensure(100));
+      VR_HIP(c, c->dWalls.ensure(VR_WALL_TABLE)); // (the launch's scalar frame behind the walls: end of this function)
       VR_HIP(c, hipMemcpy(c->dWalls.p, tbl, sizeof(tbl), hipMemcpyHostToDevice));
     }
     // rayBoundary.hpp:23-25: conditions are picked by AXIS
@@ -1524,6 +1520,35 @@ static int prepare_one(vr_context *c) {
   p.debugFlags = 0;
   if (const char *e = std::getenv("VR_DEBUG_FLAGS"))
     p.debugFlags = (uint32_t)std::atoi(e);
+  { // the launch's scalar frame, staged in LDS by the trace kernels (VR_F_*, vr_device.hpp)
+    float *f = c->frameHost;
+    auto bits = [](int32_t v) {
+      float r;
+      std::memcpy(&r, &v, 4);
+      return r;
+    };
+    f[0] = p.srcCoord;
+    f[1] = bits(p.rayDir);
+    f[2] = bits(p.firstDir);
+    f[3] = bits(p.secondDir);
+    f[4] = f[5] = 0.f; // (the records' side-array address: written by the kernel from its own argument)
+    f[6] = p.lo1;
+    f[7] = p.hi1;
+    f[8] = p.lo2;
+    f[9] = p.hi2;
+    f[10] = p.wallLoR;
+    f[11] = p.wallHiR;
+    for (int k = 0; k < 3; ++k) {
+      f[12 + k] = p.sceneLo[k];
+      f[15 + k] = p.sceneHi[k];
+    }
+    f[18] = p.pqPad;
+    f[19] = bits(p.bc0);
+    f[20] = bits(p.bc1);
+    f[21] = p.nbDist;
+    f[22] = f[23] = 0.f;
+    VR_HIP(c, hipMemcpyAsync(c->dWalls.p + 96, f, 24 * 4, hipMemcpyHostToDevice, c->stream));
+  }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (redoConfig)
     c->buildSeconds = secs; // a cheap re-prepare (new seed / ray range only) keeps the last build time

@@ -352,6 +352,16 @@ __device__ __forceinline__ void hit_clear(HitRec &h) {
 // the surface long before they could reach a wall plane, and for those the (long)
 // triangle tests are skipped.  A wall wins against geometry at equal t (closest-hit rule:
 // boundary first); among walls the lower id wins.
+// The launch's scalar frame, staged behind the walls in the kernels' LDS table (vr_api.cpp fills it at every prepare).
+// Loop-invariant kernel arguments are hoisted and held in SGPRs throughout; the spilled ones come back by v_readlane
+// at every use.  The compact ray records' decode (vr_trace.hip) reads its four scalars from here in every kernel; the
+// absorbing flat-scene kernel (8 waves per SIMD, 78 spilled SGPRs) also its wall and scene-box frame: the *_lds
+// variants below (C2 trace 6.5 -> 6.3 ms; the general kernels measured 3 % SLOWER with them and keep the arguments).
+constexpr int VR_WALL_TABLE = 120; // floats
+enum { VR_F_SRC_PLANE = 96, VR_F_RAYDIR = 97, VR_F_FIRSTDIR = 98, VR_F_SECONDDIR = 99, VR_F_EXTRA_LO = 100, VR_F_EXTRA_HI = 101,
+       VR_F_LO1 = 102 /* lo1, hi1, lo2, hi2 */, VR_F_WALL_LO_R = 106, VR_F_WALL_HI_R = 107, VR_F_SCENE_LO = 108, VR_F_SCENE_HI = 111,
+       VR_F_PQ_PAD = 114, VR_F_BC0 = 115, VR_F_BC1 = 116, VR_F_NB_DIST = 117 };
+
 __device__ __forceinline__ void hit_walls(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
                                           const V3 &d, float tnear, HitRec &h) {
   if (p.debugFlags & 8u)
@@ -379,6 +389,55 @@ __device__ __forceinline__ void hit_walls(const TraceParams &p, const float *__r
         continue;
       const float cr = getc(o, p.rayDir) + getc(d, p.rayDir) * tw;
       if (cr < p.wallLoR || cr > p.wallHiR)
+        continue;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float *w = w0 + 12 * j;
+      float t;
+      if (hit_tri(o, d, tnear, mk(w[0], w[1], w[2]), mk(w[3], w[4], w[5]), mk(w[6], w[7], w[8]),
+                  mk(w[9], w[10], w[11]), t)) {
+        if (t < hw.t) { // ascending wall id: ties keep the lower id
+          hw.t = t;
+          hw.geom = 0;
+          hw.prim = (unsigned)(2 * pair + j);
+        }
+      }
+    }
+  }
+  if (hw.geom == 0 && hw.t <= h.t)
+    h = hw;
+}
+
+// ... the same with the frame read from LDS (see above)
+__device__ __forceinline__ void hit_walls_lds(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
+                                          const V3 &d, float tnear, HitRec &h) {
+  if (p.debugFlags & 8u)
+    return;
+  HitRec hw;
+  hit_clear(hw);
+  const float tLimit = h.t * 1.001f; // (plane t below is approximate: generous margin; inf stays inf)
+  const int aRay = __float_as_int(wallS[VR_F_RAYDIR]), aFirst = __float_as_int(wallS[VR_F_FIRSTDIR]), aSecond = __float_as_int(wallS[VR_F_SECONDDIR]);
+  const float o1 = getc(o, aFirst), d1 = getc(d, aFirst);
+  const float o2 = getc(o, aSecond), d2 = getc(d, aSecond);
+#pragma unroll
+  for (int pair = 0; pair < 4; ++pair) {
+    const float *w0 = wallS + 24 * pair;
+    // the wall planes are the adjusted bbox faces: scalars, no LDS read needed to cull
+    const float W = wallS[VR_F_LO1 + pair]; // lo1, hi1, lo2, hi2
+    const float oa = pair < 2 ? o1 : o2, da = pair < 2 ? d1 : d2;
+    if (!wall_reachable(W, oa, da))
+      continue;
+    {
+      // conservative pre-tests (the approximate reciprocal is fine, the margins are far
+      // above its rounding): the plane must come before the geometry hit, and where the
+      // ray meets it, it must lie inside the wall's extent along the tracing axis (the
+      // walls span the whole adjusted bbox there)
+      const float tw = (W - oa) * __builtin_amdgcn_rcpf(da);
+      if (tw > tLimit)
+        continue;
+      const float cr = getc(o, aRay) + getc(d, aRay) * tw;
+      if (cr < wallS[VR_F_WALL_LO_R] || cr > wallS[VR_F_WALL_HI_R])
         continue;
     }
 #pragma unroll
@@ -861,15 +920,17 @@ struct PqCands {
 constexpr unsigned VR_PQ_CANDS = 52; // >= 2 * pqMaxCand + 1 (pqMaxCand <= 24, vr_api.cpp)
 
 // lst: 128 dwords of LDS private to this wave
-template <int GEO, bool CREDIT>
+// FRAME_LDS: the scene box and the padding come from the LDS frame `wallS` (see hit_walls_lds)
+template <int GEO, bool CREDIT, bool FRAME_LDS = false>
 __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
-                                              HitRec &h, volatile unsigned *lst, PqCands &cd VR_DIAG_ARGS) {
+                                              HitRec &h, volatile unsigned *lst, PqCands &cd,
+                                              const float *__restrict__ wallS VR_DIAG_ARGS) {
   const unsigned lane = threadIdx.x & 63u;
   // the ray's stretch inside the scene box
   const V3 inv = safe_inverse(d);
-  const float tx0 = (p.sceneLo[0] - o.x) * inv.x, tx1 = (p.sceneHi[0] - o.x) * inv.x;
-  const float ty0 = (p.sceneLo[1] - o.y) * inv.y, ty1 = (p.sceneHi[1] - o.y) * inv.y;
-  const float tz0 = (p.sceneLo[2] - o.z) * inv.z, tz1 = (p.sceneHi[2] - o.z) * inv.z;
+  const float tx0 = ((FRAME_LDS ? wallS[VR_F_SCENE_LO] : p.sceneLo[0]) - o.x) * inv.x, tx1 = ((FRAME_LDS ? wallS[VR_F_SCENE_HI] : p.sceneHi[0]) - o.x) * inv.x;
+  const float ty0 = ((FRAME_LDS ? wallS[VR_F_SCENE_LO + 1] : p.sceneLo[1]) - o.y) * inv.y, ty1 = ((FRAME_LDS ? wallS[VR_F_SCENE_HI + 1] : p.sceneHi[1]) - o.y) * inv.y;
+  const float tz0 = ((FRAME_LDS ? wallS[VR_F_SCENE_LO + 2] : p.sceneLo[2]) - o.z) * inv.z, tz1 = ((FRAME_LDS ? wallS[VR_F_SCENE_HI + 2] : p.sceneHi[2]) - o.z) * inv.z;
   const float tIn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
   const float tOut = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
   const bool valid = part && tIn <= tOut;
@@ -886,12 +947,13 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   float qlx = valid ? fminf(ax, bx) : big, qly = valid ? fminf(ay, by) : big, qlz = valid ? fminf(az, bz) : big;
   float qhx = valid ? fmaxf(ax, bx) : -big, qhy = valid ? fmaxf(ay, by) : -big, qhz = valid ? fmaxf(az, bz) : -big;
   wave_minmax6(qlx, qly, qlz, qhx, qhy, qhz);
-  qlx -= p.pqPad;
-  qly -= p.pqPad;
-  qlz -= p.pqPad;
-  qhx += p.pqPad;
-  qhy += p.pqPad;
-  qhz += p.pqPad;
+  const float pad = FRAME_LDS ? wallS[VR_F_PQ_PAD] : p.pqPad;
+  qlx -= pad;
+  qly -= pad;
+  qlz -= pad;
+  qhx += pad;
+  qhy += pad;
+  qhz += pad;
   // breadth-first search of the 64-ary tree: a frontier entry = {first child, child count | prims flag}
   const float4 *__restrict__ wide = reinterpret_cast<const float4 *>(p.wide);
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);

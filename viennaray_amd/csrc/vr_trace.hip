@@ -454,6 +454,7 @@ __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
 __attribute__((amdgpu_waves_per_eu(MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? 5 : VR_GENERAL_WAVES))), MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? 5 : VR_GENERAL_WAVES)))))) void
 trace_kernel(const TraceParams p) {
   constexpr bool SMALL = MODE_ == 4;
+  constexpr bool FRAME_LDS = MODE_ == 1; // (the wall / scene-box frame from LDS: hit_walls_lds, vr_device.hpp)
   constexpr int MODE = SMALL ? 0 : MODE_;
   constexpr bool ABSORB = MODE == 1 || MODE == 2;
   // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
@@ -473,7 +474,7 @@ trace_kernel(const TraceParams p) {
   // The absorbing kernel for flat scenes does without: its rounds are packets, and the extra
   // live registers would cost it the 8th wave per SIMD.
   constexpr bool CARRY = MODE != 1;
-  __shared__ float wallS[104]; // (96 .. 101: the source frame of the compact ray records, the side array's address)
+  __shared__ float wallS[VR_WALL_TABLE]; // (96 .. : the launch's scalar frame, vr_device.hpp)
   // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
   // The general kernels count five of the eight events per WAVE (a wave-uniform register += popcount of the lanes
   // that reach the count) and keep per-lane LDS words only for the three that are added as values or passed by
@@ -500,10 +501,10 @@ trace_kernel(const TraceParams p) {
   cands.rec = candS + (PQ_CREDIT ? (tid >> 6) * VR_PQ_CANDS : 0u);
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
-  if (tid < 100)
+  if (tid < VR_WALL_TABLE)
     wallS[tid] = p.wallTable[tid];
-  if (tid == 100 || tid == 101) // (read per lane at a refill: as a kernel argument the pointer would be held in SGPRs throughout)
-    wallS[tid] = __uint_as_float((unsigned)((unsigned long long)p.recExtra >> (tid == 100 ? 0 : 32)));
+  if (tid == VR_F_EXTRA_LO || tid == VR_F_EXTRA_HI) // (read per lane at a refill: as a kernel argument the pointer would be held in SGPRs throughout)
+    wallS[tid] = __uint_as_float((unsigned)((unsigned long long)p.recExtra >> (tid == VR_F_EXTRA_LO ? 0 : 32)));
 #pragma unroll
   for (int k = 0; k < (WAVEC ? 3 : 8); ++k)
     cntS[k * VR_BLOCK + tid] = 0u;
@@ -714,9 +715,9 @@ trace_kernel(const TraceParams p) {
         if (!ABSORB) {
           // compact form.  (The source frame comes from LDS, per lane: as kernel arguments these loop-invariant scalars
           //  were hoisted and held across the whole kernel — scalar spills in every instantiation.)
-          float srcPlane = wallS[96];
-          const int rd = __float_as_int(wallS[97]), fd = __float_as_int(wallS[98]);
-          const unsigned long long ex = ((unsigned long long)__float_as_uint(wallS[101]) << 32) | __float_as_uint(wallS[100]);
+          float srcPlane = wallS[VR_F_SRC_PLANE];
+          const int rd = __float_as_int(wallS[VR_F_RAYDIR]), fd = __float_as_int(wallS[VR_F_FIRSTDIR]);
+          const unsigned long long ex = ((unsigned long long)__float_as_uint(wallS[VR_F_EXTRA_HI]) << 32) | __float_as_uint(wallS[VR_F_EXTRA_LO]);
           const unsigned seed32 = tea3((unsigned)(p.batchFirst + __float_as_uint(b.y)), p.seed);
           constexpr unsigned NS = D == 3 ? 4u : 3u; // draws of the plain generator (gen_kernel)
           unsigned k = NS;
@@ -788,7 +789,7 @@ trace_kernel(const TraceParams p) {
         if (active) {
           DIAG(12);
         }
-        packetDone = pq_hit_packet<GEO, PQ_CREDIT>(p, active, org, dir, tnear, h, pqS + (tid >> 6) * 128u, cands VR_DIAG_PASS);
+        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS>(p, active, org, dir, tnear, h, pqS + (tid >> 6) * 128u, cands, wallS VR_DIAG_PASS);
         pqCredit = PQ_CREDIT && packetDone;
         pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
         pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;
@@ -841,8 +842,12 @@ trace_kernel(const TraceParams p) {
     }
 #endif
     TICK(3);
-    if (fin)
-      hit_walls(p, wallS, org, dir, tnear, h); // boundary walls, where one can come before the hit
+    if (fin) { // boundary walls, where one can come before the hit
+      if constexpr (FRAME_LDS)
+        hit_walls_lds(p, wallS, org, dir, tnear, h);
+      else
+        hit_walls(p, wallS, org, dir, tnear, h);
+    }
     TICK(4);
     // Merge same-disk credits of the wave into one atomic when that is likely to pay: rays of a
     // packet, or — sampled on one lane's target — when a good share of the wave's hits fall on
@@ -1331,9 +1336,9 @@ template <int GEO>
 __global__ void debug_intersect_kernel(const TraceParams p, const float *org, const float *dir, const float *tnear,
                                        unsigned n, int *geomID, unsigned *primID, float *t, int ordered,
                                        unsigned walkStackWaves) {
-  __shared__ float wallS[96];
+  __shared__ float wallS[VR_WALL_TABLE];
   __shared__ unsigned stackS[VR_STACK_LDS * VR_BLOCK]; // (64-thread blocks: lane columns 0..63 of the [entry][VR_BLOCK] layout)
-  for (unsigned k = threadIdx.x; k < 96; k += blockDim.x)
+  for (unsigned k = threadIdx.x; k < VR_WALL_TABLE; k += blockDim.x)
     wallS[k] = p.wallTable[k];
   __syncthreads();
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1382,8 +1387,8 @@ hipError_t launch_debug_intersect(const TraceParams &p, int geo, const float *or
 template <int D>
 __global__ void debug_process_hit_kernel(const TraceParams p, const float *org, const float *dir, const float *tfar,
                                          const unsigned *prim, unsigned n, float *outOrg, float *outDir, int *outReflect) {
-  __shared__ float wallS[96];
-  for (unsigned k = threadIdx.x; k < 96; k += blockDim.x)
+  __shared__ float wallS[VR_WALL_TABLE];
+  for (unsigned k = threadIdx.x; k < VR_WALL_TABLE; k += blockDim.x)
     wallS[k] = p.wallTable[k];
   __syncthreads();
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
