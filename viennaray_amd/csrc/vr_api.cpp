@@ -2460,7 +2460,7 @@ int vr_get_run_number(const vr_context *c, uint32_t *out) {
 // out4 = {counted instructions per second, sustained clock in Hz (median over waves),
 //         seconds (HIP events), counted instructions}
 int vr_debug_issue_rate(vr_context *c, int kind, int wavesPerSimd, uint32_t iters, double *out4) {
-  if (!c || !out4 || kind < 0 || kind > 5 || wavesPerSimd < 1 || wavesPerSimd > 8 || iters == 0)
+  if (!c || !out4 || kind < 0 || kind > 6 || wavesPerSimd < 1 || wavesPerSimd > 8 || iters == 0)
     return fail(c, VR_E_INVALID, "vr_debug_issue_rate: bad argument");
   VR_HIP(c, hipSetDevice(c->device));
   const unsigned blocks = (unsigned)c->numCUs * (unsigned)wavesPerSimd;
@@ -2482,7 +2482,7 @@ int vr_debug_issue_rate(vr_context *c, int kind, int wavesPerSimd, uint32_t iter
     if (h[3 * w + 1])
       clk.push_back((double)h[3 * w] / (double)h[3 * w + 1] * 1e8);
   std::sort(clk.begin(), clk.end());
-  const double perPass = kind >= 4 ? 24.0 : 32.0;
+  const double perPass = (kind == 4 || kind == 5) ? 24.0 : 32.0;
   const double counted = (double)waves * (double)iters * perPass;
   out4[0] = counted / (ms * 1e-3);
   out4[1] = clk.empty() ? 0.0 : clk[clk.size() / 2];

@@ -65,6 +65,22 @@ template <int KIND> __global__ __launch_bounds__(256) void issue_kernel(unsigned
 #pragma unroll
       for (unsigned j = 1; j <= 32; ++j)
         x = mt_step_v(mm, x, j);
+    } else if (KIND == 6) {
+      // the step with its high word by two more v_mad_u64_u32 chained onto the first (5 VALU + a move): faster in
+      // isolation, slower in the generator (vr_device.hpp, mt_step_v)
+      unsigned al = 0x4C957F2Du, ah = 0x5851F42Du, zero = 0u;
+      asm volatile("" : "+v"(al), "+v"(ah), "+v"(zero));
+#pragma unroll
+      for (unsigned j = 1; j <= 32; ++j) {
+        const unsigned xh = (unsigned)(x >> 32);
+        const unsigned t = (unsigned)x ^ (xh >> 30);
+        u64 r, r2, r3;
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(t), "v"(al), "s"((u64)j) : "vcc");
+        const u64 carry = ((u64)zero << 32) | (unsigned)(r >> 32);
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r2) : "v"(t), "v"(ah), "v"(carry) : "vcc");
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r3) : "v"(xh), "v"(al), "v"(r2) : "vcc");
+        x = ((u64)(unsigned)r3 << 32) | (unsigned)r;
+      }
     } else if (KIND == 3) {
       // 32 SALU per pass on four independent registers
       asm volatile(VR_REP8("s_add_u32 %0, %0, %1\n s_and_b32 %1, %1, %2\n s_lshl_b32 %2, %2, 1\n s_xor_b32 %3, %3, %0\n")
@@ -110,6 +126,7 @@ hipError_t launch_issue_kernel(int kind, unsigned blocks, unsigned iters, void *
   case 2: hipLaunchKernelGGL((issue_kernel<2>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
   case 3: hipLaunchKernelGGL((issue_kernel<3>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
   case 5: hipLaunchKernelGGL((issue_kernel<5>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
+  case 6: hipLaunchKernelGGL((issue_kernel<6>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
   default: hipLaunchKernelGGL((issue_kernel<4>), dim3(blocks), dim3(256), 0, s, iters, o, 1.0f); break;
   }
   return hipGetLastError();

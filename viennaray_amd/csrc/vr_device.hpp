@@ -126,6 +126,10 @@ __device__ __forceinline__ u64 mt_step(u64 p, unsigned j) { return 6364136223846
 // halves with the multiplier's halves held in VGPRs: v_mad_u64_u32 can then take the step index as its scalar
 // 64-bit addend (gfx9 VOP3: one scalar source per instruction) — 6 VALU per step (3 of them multiplies)
 // instead of the 7 + a 64-bit add the compiler makes of the one-line form.
+// (The high word by two more v_mad_u64_u32 chained onto the first — 5 VALU + a register move — issues in 20.1
+//  SIMD-cycles per step against 24.4 in isolation (tools/mt_step_variants.py, vr_bench.hip kind 6), but the chip
+//  then holds 2.0 - 2.27 GHz instead of 2.39, and the generator, which already runs at 1.9 GHz, got SLOWER: 4.66 ->
+//  4.8 - 4.95 ms.  The generator is bound by power, not by issue slots; v_mul_lo_u32 is the cheaper multiply.)
 struct MtMul {
   unsigned al, ah;
 };
@@ -917,11 +921,14 @@ struct PqCands {
   unsigned long long local;
   unsigned count; // wave-uniform
 };
-constexpr unsigned VR_PQ_CANDS = 52; // >= 2 * pqMaxCand + 1 (pqMaxCand <= 24, vr_api.cpp)
+constexpr unsigned VR_PQ_CANDS = 52; // >= 2 * pqMaxCand + 1 (pqMaxCand <= 24, vr_api.cpp) + the two records below
+// KEEPQ: records 50 / 51 keep the query's (padded) box {lo.xyz, -}{hi.xyz, -} for the round's follow-up segments
+// (trace_kernel, "follow-up segments"); an empty box when no ray reached the scene
+constexpr unsigned VR_PQ_BOX = 50;
 
 // lst: 128 dwords of LDS private to this wave
 // FRAME_LDS: the scene box and the padding come from the LDS frame `wallS` (see hit_walls_lds)
-template <int GEO, bool CREDIT, bool FRAME_LDS = false>
+template <int GEO, bool CREDIT, bool FRAME_LDS = false, bool KEEPQ = false>
 __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
                                               HitRec &h, volatile unsigned *lst, PqCands &cd,
                                               const float *__restrict__ wallS VR_DIAG_ARGS) {
@@ -936,9 +943,14 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   const bool valid = part && tIn <= tOut;
   cd.count = 0;
   cd.local = 0ull;
-  if (!ballot64(valid))
-    return true; // nobody reaches the scene box: every ray misses the geometry
   const float big = 3.0e38f;
+  if (!ballot64(valid)) {
+    if (KEEPQ && lane == 0u) {
+      cd.rec[VR_PQ_BOX] = make_uint4(__float_as_uint(big), __float_as_uint(big), __float_as_uint(big), 0u);
+      cd.rec[VR_PQ_BOX + 1] = make_uint4(__float_as_uint(-big), __float_as_uint(-big), __float_as_uint(-big), 0u);
+    }
+    return true; // nobody reaches the scene box: every ray misses the geometry
+  }
   // (Q starts at the ray's origin where that lies inside the box, not at tnear: the neighbour test
   //  accepts any t > 0)
   const float tQ = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
@@ -954,6 +966,10 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   qhx += pad;
   qhy += pad;
   qhz += pad;
+  if (KEEPQ && lane == 0u) {
+    cd.rec[VR_PQ_BOX] = make_uint4(__float_as_uint(qlx), __float_as_uint(qly), __float_as_uint(qlz), 0u);
+    cd.rec[VR_PQ_BOX + 1] = make_uint4(__float_as_uint(qhx), __float_as_uint(qhy), __float_as_uint(qhz), 0u);
+  }
   // breadth-first search of the 64-ary tree: a frontier entry = {first child, child count | prims flag}
   const float4 *__restrict__ wide = reinterpret_cast<const float4 *>(p.wide);
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);

@@ -455,6 +455,7 @@ __attribute__((amdgpu_waves_per_eu(MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 
 trace_kernel(const TraceParams p) {
   constexpr bool SMALL = MODE_ == 4;
   constexpr bool FRAME_LDS = MODE_ == 1; // (the wall / scene-box frame from LDS: hit_walls_lds, vr_device.hpp)
+  constexpr bool FOLLOW = MODE_ == 3;    // (follow-up segments inside the round of a packet query: end of the round)
   constexpr int MODE = SMALL ? 0 : MODE_;
   constexpr bool ABSORB = MODE == 1 || MODE == 2;
   // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
@@ -789,7 +790,7 @@ trace_kernel(const TraceParams p) {
         if (active) {
           DIAG(12);
         }
-        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS>(p, active, org, dir, tnear, h, pqS + (tid >> 6) * 128u, cands, wallS VR_DIAG_PASS);
+        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW>(p, active, org, dir, tnear, h, pqS + (tid >> 6) * 128u, cands, wallS VR_DIAG_PASS);
         pqCredit = PQ_CREDIT && packetDone;
         pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
         pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;
@@ -1180,6 +1181,76 @@ trace_kernel(const TraceParams p) {
               if (v && l < p.numData)
                 atomicAdd(&fluxAcc[(size_t)l * p.planeStride + q], v);
             }
+          }
+        }
+      }
+    }
+    if constexpr (FOLLOW) {
+      // ---- follow-up segments.  A ray that goes on after this round's event (reflected off the surface, let through
+      // a back face, turned round by a side wall) would search the geometry again in the next round — on a flat scene
+      // only to leave it at once, and the wave would pay a second packet query for it.  Where the new segment's stretch
+      // inside the scene box lies within the box Q of this round's query, the query's candidates are every primitive it
+      // can meet (a disk it hits holds a point of that stretch, hence meets Q): they are tested here, and a segment that
+      // meets none of them is finished in this round — its wall test and the miss / boundary branches of the state
+      // machine (rayTraceKernel.hpp:169-214).  A segment that does meet one is left to the next round as before.
+      // Same arithmetic, same closest-hit rule: nothing changes in the results (the parity tests run both ways,
+      // VR_DEBUG_FLAGS=256 switches this off).
+      if (pqCredit && !(p.debugFlags & 256u)) {
+        const bool again = fin && active;
+        bool inside = false, reaches = false;
+        if (again) {
+          const uint4 ql = cands.rec[VR_PQ_BOX], qh = cands.rec[VR_PQ_BOX + 1];
+          const V3 inv = safe_inverse(dir);
+          const float tx0 = (p.sceneLo[0] - org.x) * inv.x, tx1 = (p.sceneHi[0] - org.x) * inv.x;
+          const float ty0 = (p.sceneLo[1] - org.y) * inv.y, ty1 = (p.sceneHi[1] - org.y) * inv.y;
+          const float tz0 = (p.sceneLo[2] - org.z) * inv.z, tz1 = (p.sceneHi[2] - org.z) * inv.z;
+          const float tEnter = fmaxf(fminf(tx0, tx1), fminf(ty0, ty1));
+          const float tIn = fmaxf(tEnter, fmaxf(fminf(tz0, tz1), tnear));
+          const float tQ = fmaxf(tEnter, fmaxf(fminf(tz0, tz1), 0.f));
+          const float tOut = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
+          reaches = tIn <= tOut; // (as pq_hit_packet's `valid`: otherwise no part of the segment is inside the scene box)
+          const float ax = org.x + dir.x * tQ, ay = org.y + dir.y * tQ, az = org.z + dir.z * tQ;
+          const float bx = org.x + dir.x * tOut, by = org.y + dir.y * tOut, bz = org.z + dir.z * tOut;
+          // (inside Q proper: the padding absorbs the rounding of the clip, as it does for the query's own rays)
+          const float pad = p.pqPad;
+          const float lx = __uint_as_float(ql.x) + pad, ly = __uint_as_float(ql.y) + pad, lz = __uint_as_float(ql.z) + pad;
+          const float hx = __uint_as_float(qh.x) - pad, hy = __uint_as_float(qh.y) - pad, hz = __uint_as_float(qh.z) - pad;
+          inside = !reaches || (fminf(ax, bx) >= lx && fmaxf(ax, bx) <= hx && fminf(ay, by) >= ly && fmaxf(ay, by) <= hy &&
+                                fminf(az, bz) >= lz && fmaxf(az, bz) <= hz);
+        }
+        if (ballot64(inside)) {
+          bool meets = false;
+          if (ballot64(inside && reaches)) {
+            for (unsigned c = 0; c < cands.count; ++c) {
+              const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane((int)cands.rec[c].x);
+              const float4 c4 = prims[2 * (size_t)q];
+              const float4 n4 = prims[2 * (size_t)q + 1];
+              float t;
+              meets = meets || hit_disc(org, dir, tnear, c4, mk(n4.x, n4.y, n4.z), t);
+            }
+          }
+          if (inside && !(reaches && meets)) {
+            HitRec h2;
+            hit_clear(h2);
+            hit_walls(p, wallS, org, dir, tnear, h2);
+            VR_COUNT(K_TRACES, 1);
+            if (h2.geom < 0) { // miss, :172-176
+              VR_COUNT(K_NONGEO, 1);
+              active = false;
+            } else { // boundary, :206-214
+              const V3 hitPoint = mk(org.x + dir.x * h2.t, org.y + dir.y * h2.t, org.z + dir.z * h2.t);
+              if (++boundaryHits > p.maxBoundaryHits) {
+                VR_COUNT(K_TERM, 1);
+                active = false;
+              } else {
+                process_boundary_hit<D>(p, wallS, h2.prim, hitPoint, org, rayDirection, dir, active);
+              }
+            }
+            if (!active) {
+              VR_COUNT(K_BOUNDARY, boundaryHits);
+              VR_COUNT(K_REFL, numReflections);
+            }
+            start = active;
           }
         }
       }
