@@ -578,6 +578,7 @@ SCHEDULING_KNOBS = [
     {"VR_PQ_CAND": "2"},                              # ... or give up half way (found hits stay valid)
     {"VR_PQ_FRONTIER": "1"},
     {"VR_GENERAL_FLAT": "1"}, {"VR_GENERAL_FLAT": "0"},  # packet-query crediting on / off in the general kernel
+    {"VR_DEBUG_FLAGS": "256"},                        # no follow-up segments inside a packet-query round
 ]
 
 
@@ -627,6 +628,55 @@ def test_scheduling_knobs_do_not_change_results(geom, sticking, monkeypatch):
             f, i = run()
         assert i == i0, knobs
         assert (f == f0).all(), knobs
+
+
+def _rippled_surface(n=120, gd=0.5, amp=0.5, wave=2.0):
+    """A gently rippled sheet of disks (z = amp sin(x / wave) cos(y / wave), normals of the height field): flat enough
+    for the box query to carry every primary ray, tilted enough for reflected rays to meet neighbouring disks."""
+    ax = (np.arange(n) - (n - 1) / 2.0) * gd
+    x, y = np.meshgrid(ax, ax, indexing="ij")
+    z = amp * np.sin(x / wave) * np.cos(y / wave)
+    nx = -amp / wave * np.cos(x / wave) * np.cos(y / wave)
+    ny = amp / wave * np.sin(x / wave) * np.sin(y / wave)
+    nrm = np.stack([nx, ny, np.ones_like(nx)], -1).reshape(-1, 3)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pts = np.stack([x, y, z], -1).reshape(-1, 3)
+    return pts.astype(np.float32), nrm.astype(np.float32), gd
+
+
+@pytest.mark.parametrize("particle", [("diffuse", 0.1, 1.0), ("specular", 0.2, 1.0), ("specular", 0.05, 40.0)])
+@pytest.mark.parametrize("surface", ["plane", "ripple"])
+@pytest.mark.parametrize("bcs", [[BC.REFLECTIVE_BOUNDARY] * 3, [BC.PERIODIC_BOUNDARY, BC.IGNORE_BOUNDARY, BC.REFLECTIVE_BOUNDARY]])
+def test_follow_up_segments_inside_a_packet_query_round(surface, particle, bcs, monkeypatch):
+    """The general flat-scene kernel (MODE 3) finishes a continuing ray's next segment in the round of the packet query
+    that found its hit, where that segment stays inside the query's box and meets none of its candidates.  Same
+    accumulator bits and counters as without (VR_DEBUG_FLAGS=256) and as the general kernel (MODE 0); oracle parity on a
+    rippled sheet, where some follow-up segments DO meet a neighbouring disk and are left to the next round."""
+    if surface == "plane":
+        pts, nrm = vr.io.plane_grid(120, 0.5)
+        gd = 0.5
+    else:
+        pts, nrm, gd = _rippled_surface()
+    monkeypatch.setenv("VR_GENERAL_FLAT", "1")
+
+    def pair():
+        return make_pair_disks(pts, nrm, gd, 3, bcs, TD.POS_Z, particle, rays_pp=40, seed=2024)
+
+    t, o = pair()
+    err, info = compare(t, o)
+    assert t.traceMode() == 3
+    assert info["reflections"] > 0 and info["boundaryHits"] > 0
+    if surface == "ripple" and particle[0] == "diffuse" and BC.IGNORE_BOUNDARY not in bcs:  # (reflected rays do meet the surface again)
+        assert info["geometryHits"] > 1.01 * info["numRays"]
+    f0 = t.getFluxF64()
+    for knobs in ({"VR_DEBUG_FLAGS": "256"}, {"VR_GENERAL_FLAT": "0"}):
+        with monkeypatch.context() as m:
+            for k, v in knobs.items():
+                m.setenv(k, v)
+            t2, _ = pair()
+            t2.apply()
+            assert info_dict(t2) == info, knobs
+            assert (t2.getFluxF64() == f0).all(), knobs
 
 
 @pytest.mark.parametrize("sticking", [1.0, 0.3])
