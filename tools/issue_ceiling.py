@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 import viennaray_amd as vr  # noqa: E402
 
 KINDS = {0: "valu_f32_independent", 1: "valu_f32_dependent_chain", 2: "mt19937_64_seed_step",
-         3: "salu", 4: "packet_mix_24valu_16salu", 5: "independent_mix_24valu_16salu"}
+         3: "salu", 4: "packet_mix_24valu_16salu", 5: "independent_mix_24valu_16salu",
+         6: "mt_seed_step_three_chained_mad64_rejected"}
 
 
 def main():
@@ -27,7 +28,7 @@ def main():
     rows = []
     for kind, name in KINDS.items():
         for w in (1, 2, 4, 6, 7, 8):
-            r = t.debugIssueRate(kind, w, iters=40000 if kind != 2 else 20000)
+            r = t.debugIssueRate(kind, w, iters=40000 if kind not in (2, 6) else 20000)
             simds, cus = 1024, 256
             clk = r["clock_hz"]
             row = dict(kind=name, waves_per_simd=w, rate=r["rate"], clock_ghz=clk / 1e9, seconds=r["seconds"],
@@ -37,7 +38,7 @@ def main():
             else:
                 row["per_simd_cycle"] = r["rate"] / (simds * clk)
                 row["cycles_per_wave_instr"] = simds * clk / r["rate"]
-            if kind >= 4:
+            if kind in (4, 5):
                 row["salu_per_cu_cycle"] = r["rate"] * (16.0 / 24.0) / (cus * clk)
             rows.append(row)
             print(json.dumps(row))
