@@ -579,6 +579,7 @@ SCHEDULING_KNOBS = [
     {"VR_PQ_FRONTIER": "1"},
     {"VR_GENERAL_FLAT": "1"}, {"VR_GENERAL_FLAT": "0"},  # packet-query crediting on / off in the general kernel
     {"VR_DEBUG_FLAGS": "256"},                        # no follow-up segments inside a packet-query round
+    {"VR_MORTON_ANISO": "1"}, {"VR_MORTON_ANISO": "1000000"},  # Morton grid of cubes / in the scene box's proportions
 ]
 
 
@@ -677,6 +678,35 @@ def test_follow_up_segments_inside_a_packet_query_round(surface, particle, bcs, 
             t2.apply()
             assert info_dict(t2) == info, knobs
             assert (t2.getFluxF64() == f0).all(), knobs
+
+
+def test_morton_grid_keeps_its_proportions_bounded(monkeypatch):
+    """The LBVH's Morton grid follows the scene box's proportions only up to 2 : 1.  Scaled freely axis by axis, a thin
+    sheet (here 400 x 400 cells wide, one cell of relief) spends a third of the code bits on its relief and the tree cuts
+    it into contour bands that overlap everywhere in plan: 3.4 x the trace time on a 10^6-disk sheet.  Same bits either
+    way; the bounded grid must be clearly faster on the same box."""
+    pts, nrm, gd = _rippled_surface(n=400, gd=1.0, amp=0.5, wave=4.0)
+
+    def run():
+        t = vr.TraceDisk(3)
+        t.setGeometry(pts, nrm, gd)
+        t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+        t.setParticleType(vr.DiffuseParticle(0.1, "flux"))
+        t.setNumberOfRaysPerPoint(40)
+        t.setRngSeed(5)
+        best = None
+        for _ in range(3):
+            t.setRunNumber(1)
+            t.apply()
+            k = t.getRayTraceInfo().timeTraceKernel
+            best = k if best is None else min(best, k)
+        return t.getFluxF64(), info_dict(t), best
+
+    f0, i0, t0 = run()
+    monkeypatch.setenv("VR_MORTON_ANISO", "1000000")
+    f1, i1, t1 = run()
+    assert i0 == i1 and (f0 == f1).all()
+    assert t1 > 1.5 * t0, (t0, t1)
 
 
 @pytest.mark.parametrize("sticking", [1.0, 0.3])

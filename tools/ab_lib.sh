@@ -2,8 +2,8 @@
 # Same-box A/B of the working tree's library against libviennaray_amd_prev.so on chosen cases, alternating.
 # usage (on the GPU box): bash tools/ab_lib.sh flat|bounce|all
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-NEW=$PWD/viennaray_amd/libviennaray_amd.so
-OLD=$PWD/viennaray_amd/libviennaray_amd_prev.so
+NEW=${NEW_LIB:-$PWD/viennaray_amd/libviennaray_amd.so}
+OLD=${OLD_LIB:-$PWD/viennaray_amd/libviennaray_amd_prev.so}
 run() { local label=$1; shift
   for rep in 1 2; do for lib in OLD NEW; do
     echo "$label [$lib] $(VR_LIB_PATH=${!lib} "$@" 2>/dev/null | tail -1 | grep -oE 'device [0-9.]+ ms trace_kernel [0-9.]+ ms')"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times one apply() of a named fixture geometry on the GPU.
-usage: tools/case_bench.py <trench3d|trench2d|mesh|plane100> <sticking> <raysPerPoint> [repeat]
+usage: tools/case_bench.py <trench3d|trench2d|mesh|plane100|ripple<n>[a<amp>]> <sticking> <raysPerPoint> [repeat]
        tools/case_bench.py <C4|C5p|C5r> [repeat]      (SURVEY.md 8d configs, 1e8 rays)"""
 import sys, os, time
 import numpy as np
@@ -35,6 +35,21 @@ elif case == "trench2d":
     gd, p, n = trench2d()
     t = vr.TraceDisk(2); t.setGeometry(p, n, gd); t.setSourceDirection(vr.TraceDirection.POS_Y)
     t.setBoundaryConditions([vr.BoundaryCondition.PERIODIC_BOUNDARY] * 2)
+elif case.startswith("ripple"):   # ripple<n>[a<amp>]: an n x n rippled sheet of disks (amplitude in grid cells, default 1)
+    import re
+    m = re.match(r"ripple(\d+)(?:a([0-9.]+))?(?:p([0-9.]+))?$", case)   # p<f>: only a central patch of side f * n is rippled
+    n_, amp, patch = int(m.group(1)), float(m.group(2) or 1.0), float(m.group(3) or 1.0)
+    ax = (np.arange(n_) - (n_ - 1) / 2.0)
+    x, y = np.meshgrid(ax, ax, indexing="ij")
+    wave = 4.0
+    inside = ((np.abs(x) <= patch * n_ / 2) & (np.abs(y) <= patch * n_ / 2)).astype(np.float64)
+    z = inside * amp * np.sin(x / wave) * np.cos(y / wave)
+    nrm = np.stack([-inside * amp / wave * np.cos(x / wave) * np.cos(y / wave), inside * amp / wave * np.sin(x / wave) * np.sin(y / wave),
+                    np.ones_like(x)], -1).reshape(-1, 3)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    p = np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32)
+    t = vr.TraceDisk(3); t.setGeometry(p, nrm.astype(np.float32), 1.0)
+    t.setBoundaryConditions([vr.BoundaryCondition.PERIODIC_BOUNDARY] * 3)
 elif case == "plane100":
     p, n = vr.io.plane_grid(100, 1.0)
     t = vr.TraceDisk(3); t.setGeometry(p, n, 1.0); t.setBoundaryConditions([vr.BoundaryCondition.PERIODIC_BOUNDARY] * 3)

@@ -893,6 +893,9 @@ static int build_scene(vr_context *c) {
   s.geo = g.geo;
   s.D = g.D;
   s.nbDist = 2 * g.diskRadius;
+  s.mortonAniso = VR_MORTON_ANISO;
+  if (const char *e = std::getenv("VR_MORTON_ANISO"))
+    s.mortonAniso = std::max(1.f, (float)std::atof(e));
   VR_HIP(c, c->dNormal3.ensure((size_t)N * 3));
   VR_HIP(c, hipMemcpyAsync(c->dNormal3.p, g.normal3.data(), (size_t)N * 12, hipMemcpyHostToDevice, c->stream));
   if (disk) {

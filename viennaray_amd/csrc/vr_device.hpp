@@ -889,7 +889,10 @@ __device__ __forceinline__ void wave_minmax6(float &a, float &b, float &c, float
 #define VR_DPP6(ctrl)                                                                                                  \
   "v_min_f32_dpp %0, %0, %0 " ctrl "\n v_min_f32_dpp %1, %1, %1 " ctrl "\n v_min_f32_dpp %2, %2, %2 " ctrl "\n"        \
   "v_max_f32_dpp %3, %3, %3 " ctrl "\n v_max_f32_dpp %4, %4, %4 " ctrl "\n v_max_f32_dpp %5, %5, %5 " ctrl "\n"
-  asm volatile(VR_DPP6("row_shr:1 row_mask:0xf bank_mask:0xf") VR_DPP6("row_shr:2 row_mask:0xf bank_mask:0xf")
+  // (s_nop 1: the compiler does not know that the block begins with DPP reads — a VGPR written by the VALU instruction
+  //  just before it needs two wait states before a DPP instruction may read it, and nothing inserts them for inline
+  //  assembly.  Found when a second call site, scheduled differently, returned minima of stale registers now and then)
+  asm volatile("s_nop 1\n" VR_DPP6("row_shr:1 row_mask:0xf bank_mask:0xf") VR_DPP6("row_shr:2 row_mask:0xf bank_mask:0xf")
                    VR_DPP6("row_shr:4 row_mask:0xf bank_mask:0xf") VR_DPP6("row_shr:8 row_mask:0xf bank_mask:0xf")
                        VR_DPP6("row_bcast:15 row_mask:0xa bank_mask:0xf") VR_DPP6("row_bcast:31 row_mask:0xc bank_mask:0xf")
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
@@ -916,21 +919,33 @@ __device__ __forceinline__ float lane_bcast(float v, int srcLane) {
 // (checkLocalIntersection, rayTraceKernel.hpp:462-507).  Every disk a ray can be credited to is
 // among the candidates: the test only passes where the ray crosses the disk, the disk lies in the
 // scene box, and Q covers every participating ray from its origin to where it leaves that box.
+// Pointers into LDS carry their address space in the type where they are volatile or travel through a struct: address-
+// space inference leaves such accesses on GENERIC pointers, i.e. flat_load / flat_store (the slow path to LDS, waiting on
+// both memory counters) — the packet query's frontier lists were read and written that way until round 3.
+#define VR_LDS __attribute__((address_space(3)))
+typedef unsigned U4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ U4 mk_u4(unsigned x, unsigned y, unsigned z, unsigned w) {
+  U4 v;
+  v.x = x, v.y = y, v.z = z, v.w = w;
+  return v;
+}
 struct PqCands {
-  uint4 *rec;    // this wave's candidate records in LDS: {leaf position, centre.xyz as bits}, VR_PQ_CANDS entries
+  VR_LDS U4 *rec; // this wave's candidate records in LDS: {leaf position, centre.xyz as bits}, VR_PQ_CANDS entries
   unsigned long long local;
   unsigned count; // wave-uniform
+  bool box;       // KEEPQ: records VR_PQ_BOX, + 1 hold the query's box (false: no ray reached the scene, nothing stored)
 };
 constexpr unsigned VR_PQ_CANDS = 52; // >= 2 * pqMaxCand + 1 (pqMaxCand <= 24, vr_api.cpp) + the two records below
 // KEEPQ: records 50 / 51 keep the query's (padded) box {lo.xyz, -}{hi.xyz, -} for the round's follow-up segments
-// (trace_kernel, "follow-up segments"); an empty box when no ray reached the scene
+// (trace_kernel, "follow-up segments"); PqCands::box says whether there is one (stored as an "empty box", two constant
+// 16-byte tuples were hoisted out of the round loop, spilled, and reloaded from scratch in every round)
 constexpr unsigned VR_PQ_BOX = 50;
 
 // lst: 128 dwords of LDS private to this wave
 // FRAME_LDS: the scene box and the padding come from the LDS frame `wallS` (see hit_walls_lds)
 template <int GEO, bool CREDIT, bool FRAME_LDS = false, bool KEEPQ = false>
 __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
-                                              HitRec &h, volatile unsigned *lst, PqCands &cd,
+                                              HitRec &h, volatile VR_LDS unsigned *lst, PqCands &cd,
                                               const float *__restrict__ wallS VR_DIAG_ARGS) {
   const unsigned lane = threadIdx.x & 63u;
   // the ray's stretch inside the scene box
@@ -944,13 +959,9 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   cd.count = 0;
   cd.local = 0ull;
   const float big = 3.0e38f;
-  if (!ballot64(valid)) {
-    if (KEEPQ && lane == 0u) {
-      cd.rec[VR_PQ_BOX] = make_uint4(__float_as_uint(big), __float_as_uint(big), __float_as_uint(big), 0u);
-      cd.rec[VR_PQ_BOX + 1] = make_uint4(__float_as_uint(-big), __float_as_uint(-big), __float_as_uint(-big), 0u);
-    }
+  cd.box = false;
+  if (!ballot64(valid))
     return true; // nobody reaches the scene box: every ray misses the geometry
-  }
   // (Q starts at the ray's origin where that lies inside the box, not at tnear: the neighbour test
   //  accepts any t > 0)
   const float tQ = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
@@ -966,9 +977,12 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   qhx += pad;
   qhy += pad;
   qhz += pad;
-  if (KEEPQ && lane == 0u) {
-    cd.rec[VR_PQ_BOX] = make_uint4(__float_as_uint(qlx), __float_as_uint(qly), __float_as_uint(qlz), 0u);
-    cd.rec[VR_PQ_BOX + 1] = make_uint4(__float_as_uint(qhx), __float_as_uint(qhy), __float_as_uint(qhz), 0u);
+  if (KEEPQ) {
+    cd.box = true;
+    if (lane == 0u) {
+      cd.rec[VR_PQ_BOX] = mk_u4(__float_as_uint(qlx), __float_as_uint(qly), __float_as_uint(qlz), 0u);
+      cd.rec[VR_PQ_BOX + 1] = mk_u4(__float_as_uint(qhx), __float_as_uint(qhy), __float_as_uint(qhz), 0u);
+    }
   }
   // breadth-first search of the 64-ary tree: a frontier entry = {first child, child count | prims flag}
   const float4 *__restrict__ wide = reinterpret_cast<const float4 *>(p.wide);
@@ -1084,7 +1098,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
         if (CREDIT) {
           const int c = (int)tests;
           if ((int)lane == k) // (the lane that loaded the record files it: its r0 is the broadcast c4)
-            cd.rec[c] = make_uint4(qq, __float_as_uint(r0.x), __float_as_uint(r0.y), __float_as_uint(r0.z));
+            cd.rec[c] = mk_u4(qq, __float_as_uint(r0.x), __float_as_uint(r0.y), __float_as_uint(r0.z));
           // (a wave-wide early out between the cheap sign tests and the division / distance part of
           //  these two tests was measured: the extra votes and branches cost more than they save)
           if (part && local_disc_hit(o, d, c4, n))

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -515,10 +516,16 @@ void host_build_bvh(const HostGeometry &g, Bvh &bvh) {
     }
   // Morton codes of the box centres
   std::vector<uint64_t> code(n);
-  float inv[3];
-  for (int k = 0; k < 3; ++k) {
-    const float ext = shi[k] - slo[k];
-    inv[k] = ext > 0.f ? 2097151.0f / ext : 0.f;
+  float inv[3]; // (cells in the scene box's proportions, at most VR_MORTON_ANISO : 1 — as morton_kernel, vr_setup.hip)
+  {
+    float aniso = VR_MORTON_ANISO;
+    if (const char *e = std::getenv("VR_MORTON_ANISO"))
+      aniso = std::max(1.f, (float)std::atof(e));
+    const float extMax = std::max(std::max(shi[0] - slo[0], shi[1] - slo[1]), shi[2] - slo[2]);
+    for (int k = 0; k < 3; ++k) {
+      const float ext = std::max(shi[k] - slo[k], extMax / aniso);
+      inv[k] = ext > 0.f ? 2097151.0f / ext : 0.f;
+    }
   }
   for (uint32_t i = 0; i < n; ++i) {
     const float *b = &box[6 * (size_t)i];

@@ -137,8 +137,14 @@ __global__ void morton_kernel(SetupParams s) {
   const float pad = 4e-6f * fmaxf(scale, 1e-3f);
   float *b = s.box + 6 * (size_t)i;
   u64 q[3];
+  // The grid's cell has the proportions of the scene box — but only up to mortonAniso : 1.  Scaled freely axis by
+  // axis, a thin sheet (1000 x 1000 cells wide, one cell of relief) spends every third bit of the code on its relief:
+  // the tree cuts it into contour bands whose boxes overlap everywhere in plan (measured on a 10^6-disk rippled sheet:
+  // 110 pair visits and 18 leaf tests per ray, 33 ms for 3e7 rays; 9.7 ms with bounded proportions).  Cubes throughout
+  // cost the 60 x 60 x 30 trench 5 %: cells twice as fine along the short (source) axis serve it better.
+  const float extMax = fmaxf(fmaxf(shi[0] - slo[0], shi[1] - slo[1]), shi[2] - slo[2]);
   for (int k = 0; k < 3; ++k) {
-    const float ext = shi[k] - slo[k];
+    const float ext = fmaxf(shi[k] - slo[k], extMax / s.mortonAniso);
     const float inv = ext > 0.f ? 2097151.0f / ext : 0.f;
     float c = (0.5f * (b[k] + b[3 + k]) - slo[k]) * inv;
     c = fminf(fmaxf(c, 0.f), 2097151.0f);

@@ -446,6 +446,12 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 #ifndef VR_GENERAL_WAVES
 #define VR_GENERAL_WAVES 6 // waves per SIMD of the general kernel (MODE 0)
 #endif
+#ifndef VR_FLAT_ORDERED
+#define VR_FLAT_ORDERED 1  // MODE 3 walks with the ordered pair walk + carry-over (0: the escape-link walk, like MODE 1)
+#endif
+#ifndef VR_FLAT_STACK
+#define VR_FLAT_STACK VR_STACK_LDS // LDS stack entries of MODE 3's ordered walk
+#endif
 #ifndef VR_FLAT_WAVES
 #define VR_FLAT_WAVES 5    // ... of the general flat-scene kernel (MODE 3)
 #endif
@@ -469,12 +475,13 @@ trace_kernel(const TraceParams p) {
   PqCands cands;
   cands.local = 0ull;
   cands.count = 0u;
+  cands.box = false;
   cands.rec = nullptr;
   // CARRY: lanes whose BVH walk is still under way when most of the wave is done keep
   // their cursor over the state-machine / refill phase (see the round structure below).
   // The absorbing kernel for flat scenes does without: its rounds are packets, and the extra
   // live registers would cost it the 8th wave per SIMD.
-  constexpr bool CARRY = MODE != 1;
+  constexpr bool CARRY = MODE != 1 && (MODE != 3 || VR_FLAT_ORDERED);
   __shared__ float wallS[VR_WALL_TABLE]; // (96 .. : the launch's scalar frame, vr_device.hpp)
   // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
   // The general kernels count five of the eight events per WAVE (a wave-uniform register += popcount of the lanes
@@ -491,15 +498,15 @@ trace_kernel(const TraceParams p) {
   __shared__ unsigned long long candAccS[PQ_SUMS ? (VR_BLOCK / 64) * VR_PQ_CANDS * PQ_LAB : 1];
   // per-lane stack of the ordered walk, [entry][lane]; the absorbing flat-scene kernel walks rarely and keeps its
   // 8 waves per SIMD with a short LDS part (deeper entries: global slab)
-  constexpr bool ORDERED = MODE != 1; // (MODE 1 walks rarely: it keeps the escape-link walk, one register of state)
-  constexpr int SD = SMALL ? VR_SMALL_STACK : VR_STACK_LDS;
+  constexpr bool ORDERED = MODE != 1 && (MODE != 3 || VR_FLAT_ORDERED); // (MODE 1 walks rarely: it keeps the escape-link walk, one register of state)
+  constexpr int SD = SMALL ? VR_SMALL_STACK : (MODE == 3 ? VR_FLAT_STACK : VR_STACK_LDS);
   __shared__ unsigned stackS[ORDERED ? SD * VR_BLOCK : 1];
   // (MODE 4: the scene copy is the kernel's dynamic LDS — smallBytes of it, so a smaller scene leaves room for a
   //  fifth block per CU)
   extern __shared__ uint4 sceneS[];
   unsigned char *const sceneB = reinterpret_cast<unsigned char *>(sceneS);
   const unsigned tid = threadIdx.x;
-  cands.rec = candS + (PQ_CREDIT ? (tid >> 6) * VR_PQ_CANDS : 0u);
+  cands.rec = (VR_LDS U4 *)(candS + (PQ_CREDIT ? (tid >> 6) * VR_PQ_CANDS : 0u));
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
   if (tid < VR_WALL_TABLE)
@@ -790,7 +797,7 @@ trace_kernel(const TraceParams p) {
         if (active) {
           DIAG(12);
         }
-        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW>(p, active, org, dir, tnear, h, pqS + (tid >> 6) * 128u, cands, wallS VR_DIAG_PASS);
+        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + (tid >> 6) * 128u), cands, wallS VR_DIAG_PASS);
         pqCredit = PQ_CREDIT && packetDone;
         pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
         pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;
@@ -1110,7 +1117,7 @@ trace_kernel(const TraceParams p) {
       if (ballot64(creditLane)) {
         float px = 0.f, py = 0.f, pz = 0.f; // centre of this lane's closest disk
         for (unsigned c = 0; c < cands.count; ++c) {
-          const uint4 cr = cands.rec[c]; // (same address in every lane: an LDS broadcast)
+          const U4 cr = cands.rec[c]; // (same address in every lane: an LDS broadcast)
           const bool mine = h.pos == cr.x;
           px = mine ? __uint_as_float(cr.y) : px;
           py = mine ? __uint_as_float(cr.z) : py;
@@ -1128,7 +1135,7 @@ trace_kernel(const TraceParams p) {
         }
         for (unsigned c = 0; c < cands.count; ++c) {
           DIAG(6);
-          const uint4 cr = cands.rec[c];
+          const U4 cr = cands.rec[c];
           const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane((int)cr.x);
           const float dx = px - __uint_as_float(cr.y), dy = py - __uint_as_float(cr.z), dz = pz - __uint_as_float(cr.w);
           bool near = fabsf(dx) <= dist && fabsf(dy) <= dist && (p.geoD == 2 || fabsf(dz) <= dist);
@@ -1177,7 +1184,7 @@ trace_kernel(const TraceParams p) {
             const unsigned q = cands.rec[lane].x;
 #pragma unroll
             for (unsigned l = 0; l < PQ_LAB; ++l) {
-              const unsigned long long v = *(volatile unsigned long long *)&candAcc[lane * PQ_LAB + l];
+              const unsigned long long v = *(volatile VR_LDS unsigned long long *)&candAcc[lane * PQ_LAB + l];
               if (v && l < p.numData)
                 atomicAdd(&fluxAcc[(size_t)l * p.planeStride + q], v);
             }
@@ -1195,11 +1202,11 @@ trace_kernel(const TraceParams p) {
       // machine (rayTraceKernel.hpp:169-214).  A segment that does meet one is left to the next round as before.
       // Same arithmetic, same closest-hit rule: nothing changes in the results (the parity tests run both ways,
       // VR_DEBUG_FLAGS=256 switches this off).
-      if (pqCredit && !(p.debugFlags & 256u)) {
+      if (pqCredit && cands.box && !(p.debugFlags & 256u)) {
         const bool again = fin && active;
         bool inside = false, reaches = false;
         if (again) {
-          const uint4 ql = cands.rec[VR_PQ_BOX], qh = cands.rec[VR_PQ_BOX + 1];
+          const U4 ql = cands.rec[VR_PQ_BOX], qh = cands.rec[VR_PQ_BOX + 1];
           const V3 inv = safe_inverse(dir);
           const float tx0 = (p.sceneLo[0] - org.x) * inv.x, tx1 = (p.sceneHi[0] - org.x) * inv.x;
           const float ty0 = (p.sceneLo[1] - org.y) * inv.y, ty1 = (p.sceneHi[1] - org.y) * inv.y;

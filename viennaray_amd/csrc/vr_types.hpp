@@ -150,6 +150,8 @@ struct TraceParams {
 };
 
 // device-side scene setup (vr_setup.hip)
+// Morton grid of the LBVH: the cell is the scene box's proportions, but at most VR_MORTON_ANISO : 1 (see morton_kernel)
+constexpr float VR_MORTON_ANISO = 2.0f;
 struct SetupParams {
   // inputs (device copies of the caller's arrays)
   const float *disk4;     // n x {x,y,z,r}
@@ -179,6 +181,7 @@ struct SetupParams {
   uint32_t *leafOfOrig, *order;
   uint32_t *nbOff, *nbIds;
   float *wide;            // 64-ary box tree (see TraceParams::wide), (n + n/64 + ...) x 8 floats
+  float mortonAniso;      // cells of the Morton grid: at most this much finer along an axis than along the longest one
 };
 
 // particle kinds of the device registry (include/viennaray_amd.h: VR_PARTICLE_*)
