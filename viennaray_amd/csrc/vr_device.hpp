@@ -219,7 +219,8 @@ template <int K> __device__ __forceinline__ void mt_first_outputs(unsigned seed,
 // (The two out-of-line tier-2 routines take the slab and the seed BY VALUE: handed a reference to the engine, the
 //  whole struct had to live in scratch memory — every draw of the streaming tier stored its counter there and the
 //  reflection loop waited on the vector-memory counter once per iteration.)
-__device__ __noinline__ void rng_tier2_build(u64 *s, unsigned seed) {
+typedef __attribute__((address_space(1))) u64 GlobalU64; // (the tier-2 state is global memory: not through flat instructions)
+__device__ __noinline__ void rng_tier2_build(GlobalU64 *s, unsigned seed) {
   u64 x = seed;
   s[0] = x;
   for (int j = 1; j < 312; ++j) {
@@ -228,7 +229,7 @@ __device__ __noinline__ void rng_tier2_build(u64 *s, unsigned seed) {
   }
 }
 
-__device__ __noinline__ void rng_tier2_twist(u64 *s) {
+__device__ __noinline__ void rng_tier2_twist(GlobalU64 *s) {
   u64 cur = s[0];
   for (int i = 0; i < 156; ++i) {
     u64 nxt = s[(i + 1) * 64];
@@ -253,21 +254,21 @@ __device__ __forceinline__ u64 rng_next(Rng &r, unsigned &tier2Count) {
     return v;
   }
   if (r.pos == 0xFFFFFFFFu) {
-    rng_tier2_build(r.scratch, r.seed);
-    rng_tier2_twist(r.scratch);
+    rng_tier2_build((GlobalU64 *)r.scratch, r.seed);
+    rng_tier2_twist((GlobalU64 *)r.scratch);
     unsigned skip = r.k; // outputs already consumed by the streaming tier
     while (skip >= 312u) {
-      rng_tier2_twist(r.scratch);
+      rng_tier2_twist((GlobalU64 *)r.scratch);
       skip -= 312u;
     }
     r.pos = skip;
     ++tier2Count;
   }
   if (r.pos >= 312u) {
-    rng_tier2_twist(r.scratch);
+    rng_tier2_twist((GlobalU64 *)r.scratch);
     r.pos = 0;
   }
-  u64 v = mt_temper(r.scratch[r.pos * 64]);
+  u64 v = mt_temper(((GlobalU64 *)r.scratch)[r.pos * 64]);
   ++r.pos;
   ++r.k;
   return v;

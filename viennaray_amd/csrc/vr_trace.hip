@@ -731,7 +731,8 @@ trace_kernel(const TraceParams p) {
           unsigned k = NS;
           u64 lo;
           if (ex) { // a source with its own origin plane / draw count: the side array has them and s[k]
-            const float4 e = reinterpret_cast<const float4 *>(ex)[__float_as_uint(b.y)];
+            typedef float F4 __attribute__((ext_vector_type(4)));
+            const F4 e = reinterpret_cast<const __attribute__((address_space(1))) F4 *>(ex)[__float_as_uint(b.y)]; // (global, not flat)
             srcPlane = e.x;
             k = __float_as_uint(e.y);
             lo = ((u64)__float_as_uint(e.w) << 32) | __float_as_uint(e.z);
@@ -1052,7 +1053,12 @@ trace_kernel(const TraceParams p) {
               // the reference makes before that test (Q2) are not observable.
               active = false;
             } else {
-              float sticking = p.primSticking ? primSticking[h.pos] : p.sticking;
+              // (not `p.primSticking ? primSticking[h.pos] : p.sticking`: the compiler makes that ONE load from a selected
+              //  address — a generic pointer, i.e. a flat_load per reflection that waits on both memory counters)
+              float sticking = p.sticking;
+              asm volatile("" : "+s"(sticking)); // (a value in a register, not a second address to choose from)
+              if (p.primSticking)
+                sticking = primSticking[h.pos];
               if (EXT) // (a registry model may make it depend on the primitive and the caller's global data)
                 sticking = Particles::sticking<EXT_FULL>(p.particleKind, model_ctx(p), h.prim, sticking);
               const float wAfter = rayWeight - rayWeight * sticking;
