@@ -440,9 +440,6 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 // MODE 4: MODE 0 for scenes of a few hundred primitives (2-D simulations): pair nodes, primitive records,
 // neighbourhood and flux accumulators are staged in LDS (VR_SMALL_LDS bytes per block) and every access of the
 // round but the ray records stays there; no packets (a per-lane walk over LDS nodes is cheaper than their set-up).
-#ifndef VR_WAVE_COUNTERS
-#define VR_WAVE_COUNTERS 0
-#endif
 #ifndef VR_GENERAL_WAVES
 #define VR_GENERAL_WAVES 6 // waves per SIMD of the general kernel (MODE 0)
 #endif
@@ -483,12 +480,10 @@ trace_kernel(const TraceParams p) {
   // live registers would cost it the 8th wave per SIMD.
   constexpr bool CARRY = MODE != 1 && (MODE != 3 || VR_FLAT_ORDERED);
   __shared__ float wallS[VR_WALL_TABLE]; // (96 .. : the launch's scalar frame, vr_device.hpp)
-  // per-lane event counters live in LDS (fire-and-forget ds_add), not in 7 VGPRs
-  // The general kernels count five of the eight events per WAVE (a wave-uniform register += popcount of the lanes
-  // that reach the count) and keep per-lane LDS words only for the three that are added as values or passed by
-  // reference: 5 KB of LDS less per block — what stood between the general kernel and a 7th wave per SIMD.
-  constexpr bool WAVEC = (VR_WAVE_COUNTERS != 0) && !ABSORB;
-  __shared__ unsigned cntS[(WAVEC ? 3 : 8) * VR_BLOCK];
+  // per-lane event counters live in LDS (fire-and-forget ds_add), not in 8 VGPRs.  (Five of them counted per WAVE in
+  // scalar registers — 5 KB of LDS less, room for a 7th block per CU — was built and measured in round 3: slower at
+  // 7 waves per SIMD and at 6; removed.)
+  __shared__ unsigned cntS[8 * VR_BLOCK];
   __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier lists
   __shared__ uint4 candS[PQ_CREDIT ? (VR_BLOCK / 64) * VR_PQ_CANDS : 1]; // ... and candidate records (pq_credit)
   // ... and, where the credits of a round carry different weights (the general kernels), one int64 sum per candidate
@@ -514,7 +509,7 @@ trace_kernel(const TraceParams p) {
   if (tid == VR_F_EXTRA_LO || tid == VR_F_EXTRA_HI) // (read per lane at a refill: as a kernel argument the pointer would be held in SGPRs throughout)
     wallS[tid] = __uint_as_float((unsigned)((unsigned long long)p.recExtra >> (tid == VR_F_EXTRA_LO ? 0 : 32)));
 #pragma unroll
-  for (int k = 0; k < (WAVEC ? 3 : 8); ++k)
+  for (int k = 0; k < 8; ++k)
     cntS[k * VR_BLOCK + tid] = 0u;
   if (SMALL) {
     // stage the scene (the offsets are multiples of 16 bytes; vr_apply_prepare checked that it fits)
@@ -543,16 +538,8 @@ trace_kernel(const TraceParams p) {
   }
   __syncthreads();
   unsigned *const cnt = cntS + tid; // counter k of this lane: cnt[k * VR_BLOCK]
-  // (per-lane slots first: with WAVEC only K_BOUNDARY, K_REFL, K_TIER2 have one)
   enum { K_BOUNDARY = 0, K_REFL, K_TIER2, K_TRACES, K_NONGEO, K_GEO, K_TERM, K_PARTICLE };
-  unsigned waveCnt[5] = {0u, 0u, 0u, 0u, 0u}; // WAVEC: K_TRACES .. K_PARTICLE, wave-uniform
-#define VR_COUNT(k, v)                                                                                                 \
-  do {                                                                                                                 \
-    if constexpr (WAVEC && (k) >= K_TRACES)                                                                            \
-      waveCnt[(k)-K_TRACES] += (unsigned)__popcll(ballot64(true));                                                      \
-    else                                                                                                               \
-      atomicAdd(&cnt[(k)*VR_BLOCK], (unsigned)(v));                                                                    \
-  } while (0)
+#define VR_COUNT(k, v) atomicAdd(&cnt[(k)*VR_BLOCK], (unsigned)(v))
 
   // scene data: global memory, or (MODE 4) the block's LDS copies
   const float4 *__restrict__ prims = SMALL ? reinterpret_cast<const float4 *>(sceneB + p.smallOff[1])
@@ -1292,11 +1279,7 @@ trace_kernel(const TraceParams p) {
   }
 #endif
   // (slot order of vr_types.hpp: traces, nongeo, geo, particle, boundary, reflections, terminated, tier2)
-  auto total = [&](int k) -> unsigned { // this lane's share of counter k (WAVEC: lane 0 carries the wave's)
-    if (WAVEC && k >= K_TRACES)
-      return lane == 0 ? waveCnt[k - K_TRACES] : 0u;
-    return cnt[k * VR_BLOCK];
-  };
+  auto total = [&](int k) -> unsigned { return cnt[k * VR_BLOCK]; }; // this lane's share of counter k
   const unsigned vals[8] = {total(K_TRACES), total(K_NONGEO), total(K_GEO),  total(K_PARTICLE),
                             total(K_BOUNDARY), total(K_REFL), total(K_TERM), total(K_TIER2)};
 #undef VR_COUNT
