@@ -122,17 +122,29 @@ def workload(name, device=0, sticking=None):
     from viennaray_amd import io
     BC = vr.BoundaryCondition
     D = 3
-    if name in ("C2", "C1_plane100"):
-        n = 1000 if name == "C2" else 100
+    if name in ("C2", "C1_plane100", "C2_rippled"):
+        n = 100 if name == "C1_plane100" else 1000
         s = 1.0 if sticking is None else sticking
         if name == "C1_plane100":
             s = 0.1 if sticking is None else sticking
         pts, nrm = io.plane_grid(n, 1.0)
+        if name == "C2_rippled":
+            # NOT a BASELINE config: C2's plane with half a grid cell of relief (z = 0.5 sin(x/4) cos(y/4), normals of the
+            # height field) — what the headline's flat-scene kernels do on a surface that is not perfectly flat
+            x, y = pts[:, 0].astype(np.float64), pts[:, 1].astype(np.float64)
+            amp, wave = 0.5, 4.0
+            pts = pts.copy()
+            pts[:, 2] = (amp * np.sin(x / wave) * np.cos(y / wave)).astype(np.float32)
+            nv = np.stack([-amp / wave * np.cos(x / wave) * np.cos(y / wave), amp / wave * np.sin(x / wave) * np.sin(y / wave),
+                           np.ones_like(x)], -1)
+            nrm = (nv / np.linalg.norm(nv, axis=1, keepdims=True)).astype(np.float32)
         t = vr.TraceDisk(3, device=device)
         t.setGeometry(pts, nrm, 1.0)
         t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
         t.setParticleType(vr.DiffuseParticle(s, "flux"))
         desc = f"P({n}) {n * n} disks, DiffuseParticle sticking {s}, cosine source, PERIODIC x/y"
+        if name == "C2_rippled":
+            desc = "NOT a BASELINE config: " + desc + ", rippled by half a grid cell"
 
         def mk_oracle(po):
             o = po.Oracle()
@@ -474,7 +486,9 @@ def main():
                          dict(name="C1_trench3d", rays=57_838_000, sample=0, counters_key="C1_trench3d"),
                          dict(name="C4", rays=100_000_000, sample=1_000_000, counters_key="C4"),
                          dict(name="C5p", rays=100_000_000, sample=1_000_000, counters_key="C5p"),
-                         dict(name="C5r", rays=100_000_000, sample=1_000_000))
+                         dict(name="C5r", rays=100_000_000, sample=1_000_000),
+                         dict(name="C2_rippled", rays=args.rays, sample=1_000_000, sticking=1.0),
+                         dict(name="C2_rippled", rays=args.rays, sample=1_000_000, sticking=0.1))
                 for cs in cases:
                     label = cs.pop("label", None)
                     if args.no_parity:

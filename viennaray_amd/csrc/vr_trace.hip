@@ -444,10 +444,8 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 #define VR_GENERAL_WAVES 6 // waves per SIMD of the general kernel (MODE 0)
 #endif
 #ifndef VR_FLAT_ORDERED
-#define VR_FLAT_ORDERED 1  // MODE 3 walks with the ordered pair walk + carry-over (0: the escape-link walk, like MODE 1)
-#endif
-#ifndef VR_FLAT_STACK
-#define VR_FLAT_STACK VR_STACK_LDS // LDS stack entries of MODE 3's ordered walk
+#define VR_FLAT_ORDERED 1  // MODE 3 walks with the ordered pair walk + carry-over (0: the escape-link walk, like MODE 1 —
+                           // with VR_FLAT_WAVES=6 faster on a perfectly flat scene, 15 - 30 % slower on a plane with a bump: DESIGN.md 7)
 #endif
 #ifndef VR_FLAT_WAVES
 #define VR_FLAT_WAVES 5    // ... of the general flat-scene kernel (MODE 3)
@@ -494,7 +492,7 @@ trace_kernel(const TraceParams p) {
   // per-lane stack of the ordered walk, [entry][lane]; the absorbing flat-scene kernel walks rarely and keeps its
   // 8 waves per SIMD with a short LDS part (deeper entries: global slab)
   constexpr bool ORDERED = MODE != 1 && (MODE != 3 || VR_FLAT_ORDERED); // (MODE 1 walks rarely: it keeps the escape-link walk, one register of state)
-  constexpr int SD = SMALL ? VR_SMALL_STACK : (MODE == 3 ? VR_FLAT_STACK : VR_STACK_LDS);
+  constexpr int SD = SMALL ? VR_SMALL_STACK : VR_STACK_LDS;
   __shared__ unsigned stackS[ORDERED ? SD * VR_BLOCK : 1];
   // (MODE 4: the scene copy is the kernel's dynamic LDS — smallBytes of it, so a smaller scene leaves room for a
   //  fifth block per CU)
