@@ -499,7 +499,11 @@ trace_kernel(const TraceParams p) {
   extern __shared__ uint4 sceneS[];
   unsigned char *const sceneB = reinterpret_cast<unsigned char *>(sceneS);
   const unsigned tid = threadIdx.x;
-  cands.rec = (VR_LDS U4 *)(candS + (PQ_CREDIT ? (tid >> 6) * VR_PQ_CANDS : 0u));
+  // (the wave's index as a SCALAR: the per-wave tables' addresses are then wave-uniform values the compiler keeps in
+  //  SGPRs — as per-lane values one of them was spilled and came back from scratch three times a round, each reload
+  //  waiting for every atomic and load the wave had in flight)
+  const unsigned waveInBlock = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  cands.rec = (VR_LDS U4 *)(candS + (PQ_CREDIT ? waveInBlock * VR_PQ_CANDS : 0u));
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
   if (tid < VR_WALL_TABLE)
@@ -783,7 +787,7 @@ trace_kernel(const TraceParams p) {
         if (active) {
           DIAG(12);
         }
-        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + (tid >> 6) * 128u), cands, wallS VR_DIAG_PASS);
+        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + waveInBlock * 128u), cands, wallS VR_DIAG_PASS);
         pqCredit = PQ_CREDIT && packetDone;
         pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
         pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;
@@ -1118,6 +1122,8 @@ trace_kernel(const TraceParams p) {
         // General kernels: the lanes crediting candidate c add their fixed-point weights to the wave's LDS sum of c
         // (ds_add_u64: exact, any order) and afterwards lane c sends candidate c's total to HBM — ONE wave instruction
         // of global atomics per round and label instead of one atomic per candidate and distinct weight.
+        // (from the per-lane wave index: with a wave-uniform ADDRESS the compiler turns these LDS atomics into a reduction
+        //  over the wave plus one atomic — more work than the two or three lanes that credit a candidate; C2 0.1 +19 %)
         unsigned long long *const candAcc = candAccS + (PQ_SUMS ? (tid >> 6) * (VR_PQ_CANDS * PQ_LAB) : 0u);
         if (PQ_SUMS) {
           for (unsigned k = lane; k < cands.count * PQ_LAB; k += 64u)
