@@ -444,11 +444,14 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 #define VR_GENERAL_WAVES 6 // waves per SIMD of the general kernel (MODE 0)
 #endif
 #ifndef VR_FLAT_ORDERED
-#define VR_FLAT_ORDERED 1  // MODE 3 walks with the ordered pair walk + carry-over (0: the escape-link walk, like MODE 1 —
-                           // with VR_FLAT_WAVES=6 faster on a perfectly flat scene, 15 - 30 % slower on a plane with a bump: DESIGN.md 7)
+#define VR_FLAT_ORDERED 0  // MODE 3 walks like MODE 1: the escape-link walk, no carry-over (1: the ordered pair walk).  It runs
+                           // only on scenes whose box is thin (vr_api.cpp: flatScene), where a wave walks in the 5 % of its
+                           // rounds whose query gives up; without the walk's 12 KB of LDS stack and ~10 VGPRs the kernel
+                           // takes 6 waves per SIMD: C2 0.1 10.9 -> 10.0 ms.  (Forced onto a scene with relief
+                           // — VR_GENERAL_FLAT=1 — it is 15 - 30 % slower than with the ordered walk at 5 waves.)
 #endif
 #ifndef VR_FLAT_WAVES
-#define VR_FLAT_WAVES 5    // ... of the general flat-scene kernel (MODE 3)
+#define VR_FLAT_WAVES 6    // ... of the general flat-scene kernel (MODE 3)
 #endif
 template <int D, int GEO, int PARTICLE, int MODE_>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
