@@ -935,12 +935,18 @@ struct PqCands {
   unsigned long long local;
   unsigned count; // wave-uniform
   bool box;       // KEEPQ: records VR_PQ_BOX, + 1 hold the query's box (false: no ray reached the scene, nothing stored)
+  unsigned mine;  // per lane: the candidate that is this lane's closest hit so far (valid where the hit came from the query)
 };
 constexpr unsigned VR_PQ_CANDS = 52; // >= 2 * pqMaxCand + 1 (pqMaxCand <= 24, vr_api.cpp) + the two records below
 // KEEPQ: records 50 / 51 keep the query's (padded) box {lo.xyz, -}{hi.xyz, -} for the round's follow-up segments
 // (trace_kernel, "follow-up segments"); PqCands::box says whether there is one (stored as an "empty box", two constant
 // 16-byte tuples were hoisted out of the round loop, spilled, and reloaded from scratch in every round)
 constexpr unsigned VR_PQ_BOX = 50;
+// records VR_PQ_NRM + c: candidate c's {normal.xyz, radius} — with record c everything the state machine (normal of the
+// closest disk), the crediting and the follow-up segments need of a candidate, read from LDS instead of from its
+// primitive record in global memory
+constexpr unsigned VR_PQ_NRM = 52;
+constexpr unsigned VR_PQ_RECORDS = 2 * 52;
 
 // lst: 128 dwords of LDS private to this wave
 // FRAME_LDS: the scene box and the padding come from the LDS frame `wallS` (see hit_walls_lds)
@@ -1095,11 +1101,14 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
         const V3 n = mk(lane_bcast(r1.x, k), lane_bcast(r1.y, k), lane_bcast(r1.z, k));
         const unsigned orig = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(r1.w), k);
         const bool ok = hit_disc(o, d, tnear, c4, n, t);
-        hit_update(h, part && ok, t, orig, qq);
+        const bool took = hit_update(h, part && ok, t, orig, qq);
         if (CREDIT) {
           const int c = (int)tests;
-          if ((int)lane == k) // (the lane that loaded the record files it: its r0 is the broadcast c4)
+          cd.mine = took ? (unsigned)c : cd.mine;
+          if ((int)lane == k) { // (the lane that loaded the record files it: its r0 / r1 are the broadcast c4 / n)
             cd.rec[c] = mk_u4(qq, __float_as_uint(r0.x), __float_as_uint(r0.y), __float_as_uint(r0.z));
+            cd.rec[VR_PQ_NRM + c] = mk_u4(__float_as_uint(r1.x), __float_as_uint(r1.y), __float_as_uint(r1.z), __float_as_uint(r0.w));
+          }
           // (a wave-wide early out between the cheap sign tests and the division / distance part of
           //  these two tests was measured: the extra votes and branches cost more than they save)
           if (part && local_disc_hit(o, d, c4, n))

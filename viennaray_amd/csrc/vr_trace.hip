@@ -474,6 +474,7 @@ trace_kernel(const TraceParams p) {
   cands.local = 0ull;
   cands.count = 0u;
   cands.box = false;
+  cands.mine = 0u;
   cands.rec = nullptr;
   // CARRY: lanes whose BVH walk is still under way when most of the wave is done keep
   // their cursor over the state-machine / refill phase (see the round structure below).
@@ -486,7 +487,7 @@ trace_kernel(const TraceParams p) {
   // 7 waves per SIMD and at 6; removed.)
   __shared__ unsigned cntS[8 * VR_BLOCK];
   __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier lists
-  __shared__ uint4 candS[PQ_CREDIT ? (VR_BLOCK / 64) * VR_PQ_CANDS : 1]; // ... and candidate records (pq_credit)
+  __shared__ uint4 candS[PQ_CREDIT ? (VR_BLOCK / 64) * VR_PQ_RECORDS : 1]; // ... and candidate records (pq_credit)
   // ... and, where the credits of a round carry different weights (the general kernels), one int64 sum per candidate
   // and data label (two labels here; further ones are summed over the wave in registers)
   constexpr bool PQ_SUMS = PQ_CREDIT && !ABSORB;
@@ -506,7 +507,7 @@ trace_kernel(const TraceParams p) {
   //  SGPRs — as per-lane values one of them was spilled and came back from scratch three times a round, each reload
   //  waiting for every atomic and load the wave had in flight)
   const unsigned waveInBlock = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  cands.rec = (VR_LDS U4 *)(candS + (PQ_CREDIT ? waveInBlock * VR_PQ_CANDS : 0u));
+  cands.rec = (VR_LDS U4 *)(candS + (PQ_CREDIT ? waveInBlock * VR_PQ_RECORDS : 0u));
   const unsigned lane = tid & 63u;
   const unsigned gwave = (blockIdx.x * VR_BLOCK + tid) >> 6;
   if (tid < VR_WALL_TABLE)
@@ -908,8 +909,13 @@ trace_kernel(const TraceParams p) {
           // geometry hit
           V3 geomNormal;
           if (GEO == 0) {
-            const float4 n4 = prims[2 * h.pos + 1];
-            geomNormal = mk(n4.x, n4.y, n4.z);
+            if (PQ_CREDIT && pqCredit) { // (found by the packet query: the candidate's record in LDS, not a dependent global load)
+              const U4 nr = cands.rec[VR_PQ_NRM + cands.mine];
+              geomNormal = mk(__uint_as_float(nr.x), __uint_as_float(nr.y), __uint_as_float(nr.z));
+            } else {
+              const float4 n4 = prims[2 * h.pos + 1];
+              geomNormal = mk(n4.x, n4.y, n4.z);
+            }
           } else {
             geomNormal = mk(prims[4 * h.pos + 1].w, prims[4 * h.pos + 2].w, prims[4 * h.pos + 3].w);
           }
@@ -1113,14 +1119,9 @@ trace_kernel(const TraceParams p) {
       // evaluated on the same floats) and its ray passes the neighbour test on q.  All lanes
       // crediting q add to ONE address: a single atomic (absorbing: count x unit weight).
       if (ballot64(creditLane)) {
-        float px = 0.f, py = 0.f, pz = 0.f; // centre of this lane's closest disk
-        for (unsigned c = 0; c < cands.count; ++c) {
-          const U4 cr = cands.rec[c]; // (same address in every lane: an LDS broadcast)
-          const bool mine = h.pos == cr.x;
-          px = mine ? __uint_as_float(cr.y) : px;
-          py = mine ? __uint_as_float(cr.z) : py;
-          pz = mine ? __uint_as_float(cr.w) : pz;
-        }
+        // centre of this lane's closest disk
+        const U4 own = cands.rec[creditLane ? cands.mine : 0u];
+        const float px = __uint_as_float(own.y), py = __uint_as_float(own.z), pz = __uint_as_float(own.w);
         const float dist = p.nbDist, dist2 = dist * dist;
         // General kernels: the lanes crediting candidate c add their fixed-point weights to the wave's LDS sum of c
         // (ds_add_u64: exact, any order) and afterwards lane c sends candidate c's total to HBM — ONE wave instruction
@@ -1229,11 +1230,10 @@ trace_kernel(const TraceParams p) {
           bool meets = false;
           if (ballot64(inside && reaches)) {
             for (unsigned c = 0; c < cands.count; ++c) {
-              const unsigned q = (unsigned)__builtin_amdgcn_readfirstlane((int)cands.rec[c].x);
-              const float4 c4 = prims[2 * (size_t)q];
-              const float4 n4 = prims[2 * (size_t)q + 1];
+              const U4 cr = cands.rec[c], nr = cands.rec[VR_PQ_NRM + c]; // (LDS broadcasts)
+              const float4 c4 = make_float4(__uint_as_float(cr.y), __uint_as_float(cr.z), __uint_as_float(cr.w), __uint_as_float(nr.w));
               float t;
-              meets = meets || hit_disc(org, dir, tnear, c4, mk(n4.x, n4.y, n4.z), t);
+              meets = meets || hit_disc(org, dir, tnear, c4, mk(__uint_as_float(nr.x), __uint_as_float(nr.y), __uint_as_float(nr.z)), t);
             }
           }
           if (inside && !(reaches && meets)) {
