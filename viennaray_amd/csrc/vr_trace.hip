@@ -450,12 +450,15 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
                            // takes 6 waves per SIMD: C2 0.1 10.9 -> 10.0 ms.  (Forced onto a scene with relief
                            // — VR_GENERAL_FLAT=1 — it is 15 - 30 % slower than with the ordered walk at 5 waves.)
 #endif
+#ifndef VR_SMALL_WAVES
+#define VR_SMALL_WAVES 5   // ... of the LDS-resident kernel (MODE 4; 6: C5 20.15 -> 21.9 ms)
+#endif
 #ifndef VR_FLAT_WAVES
 #define VR_FLAT_WAVES 6    // ... of the general flat-scene kernel (MODE 3)
 #endif
 template <int D, int GEO, int PARTICLE, int MODE_>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
-__attribute__((amdgpu_waves_per_eu(MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? 5 : VR_GENERAL_WAVES))), MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? 5 : VR_GENERAL_WAVES)))))) void
+__attribute__((amdgpu_waves_per_eu(MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? VR_SMALL_WAVES : VR_GENERAL_WAVES))), MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? VR_SMALL_WAVES : VR_GENERAL_WAVES)))))) void
 trace_kernel(const TraceParams p) {
   constexpr bool SMALL = MODE_ == 4;
   constexpr bool FRAME_LDS = MODE_ == 1; // (the wall / scene-box frame from LDS: hit_walls_lds, vr_device.hpp)
