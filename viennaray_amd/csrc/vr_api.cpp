@@ -229,7 +229,12 @@ struct vr_context {
   uint32_t numBins = 0;
   uint64_t rayFirstLaunch = 0, rayEndLaunch = 0;
   bool absorb = true;
-  float frameHost[24] = {0};  // the scalar frame behind the wall table (staging buffer of its upload)
+  float frameHost[32] = {0};  // the scalar frame behind the wall table (staging buffer of its upload)
+  DevBuf<uint32_t> dHfRaw;    // height field over the source plane (HeightFieldParams): built for particles that reflect
+  DevBuf<float> dHf;
+  HeightFieldParams hf{};
+  uint32_t hfBuild = 0xFFFFFFFFu; // the bvhBuilds count and source frame it was made for
+  int hfAxes[4] = {-1, -1, -1, -1};
   bool recExtra = false;      // non-absorbing particle under a tilted / grid / host source: the records' side array
   DevBuf<float> dRecExtra;
   std::vector<hipEvent_t> evK; // trace-kernel event pairs, one per batch
@@ -306,6 +311,8 @@ void vr_destroy(vr_context *c) {
   c->dPrimSticking.release();
   c->dNbOff.release();
   c->dNbIds.release();
+  c->dHfRaw.release();
+  c->dHf.release();
   c->dLeafOfOrig.release();
   c->dFluxAcc.release();
   c->dFluxOrig.release();
@@ -1555,8 +1562,60 @@ static int prepare_one(vr_context *c) {
     f[19] = bits(p.bc0);
     f[20] = bits(p.bc1);
     f[21] = p.nbDist;
-    f[22] = f[23] = 0.f;
-    VR_HIP(c, hipMemcpyAsync(c->dWalls.p + 96, f, 24 * 4, hipMemcpyHostToDevice, c->stream));
+    for (int k = 22; k < 32; ++k)
+      f[k] = 0.f;
+    // height field over the source plane: for particles that go on after a hit ("segments that rise clear", vr_trace.hip)
+    if (!c->absorb && c->geo.numPrims && !std::getenv("VR_NO_HEIGHT_FIELD")) {
+      const bool stale = c->hfBuild != c->bvhBuilds || c->hfAxes[0] != c->ts[0] || c->hfAxes[1] != c->ts[1] ||
+                         c->hfAxes[2] != c->ts[2] || c->hfAxes[3] != c->ts[3];
+      if (stale) {
+        HeightFieldParams &q = c->hf;
+        q.prims = c->dPrims.p;
+        q.n = c->geo.numPrims;
+        q.geo = c->geo.geo;
+        q.ax = c->ts[0];
+        q.a1 = c->ts[1];
+        q.a2 = c->ts[2];
+        q.sign = c->ts[3] ? 1.f : -1.f; // (ts[3]: the source plane lies at the max side)
+        const float ext1 = c->sceneHi[q.a1] - c->sceneLo[q.a1], ext2 = D == 3 ? c->sceneHi[q.a2] - c->sceneLo[q.a2] : 0.f;
+        float cells = 4.f; // (tile side in grid cells; sweep 2 / 3 / 4 / 6 / 8: see DESIGN.md 7)
+        if (const char *e = std::getenv("VR_HF_TILE"))
+          cells = std::max(0.25f, (float)std::atof(e));
+        float tile = std::max(cells * c->geo.gridDelta, std::max(ext1, ext2) / 256.f);
+        if (!(tile > 0.f))
+          tile = 1.f;
+        q.lo1 = c->sceneLo[q.a1];
+        q.lo2 = D == 3 ? c->sceneLo[q.a2] : 0.f;
+        q.invTile = 1.f / tile;
+        q.nx = std::max(1, std::min(256, (int)std::ceil(ext1 / tile)));
+        q.ny = D == 3 ? std::max(1, std::min(256, (int)std::ceil(ext2 / tile))) : 1;
+        float scale = 1e-3f;
+        for (int k = 0; k < 3; ++k)
+          scale = std::max(scale, std::max(std::fabs(c->sceneLo[k]), std::fabs(c->sceneHi[k])));
+        q.pad = 8e-7f * scale; // (a dozen ulp of the largest coordinate: see DESIGN.md 5.2)
+        VR_HIP(c, c->dHfRaw.ensure((size_t)q.nx * q.ny));
+        VR_HIP(c, c->dHf.ensure((size_t)q.nx * q.ny));
+        q.raw = c->dHfRaw.p;
+        q.field = c->dHf.p;
+        VR_HIP(c, launch_height_field(q, c->stream));
+        c->hfBuild = c->bvhBuilds;
+        for (int k = 0; k < 4; ++k)
+          c->hfAxes[k] = c->ts[k];
+      }
+      const HeightFieldParams &q = c->hf;
+      f[22] = q.lo1;
+      f[23] = q.lo2;
+      f[24] = q.invTile;
+      f[25] = 1.f / q.invTile;
+      f[26] = (q.sign > 0.f ? c->sceneHi[q.ax] : -c->sceneLo[q.ax]); // above this nothing is left (the BVH's root box)
+      f[27] = q.sign;
+      f[28] = bits(q.nx);
+      f[29] = bits(q.ny);
+      const uint64_t addr = (uint64_t)(uintptr_t)q.field;
+      f[30] = bits((int32_t)(uint32_t)(addr & 0xFFFFFFFFull));
+      f[31] = bits((int32_t)(uint32_t)(addr >> 32));
+    }
+    VR_HIP(c, hipMemcpyAsync(c->dWalls.p + 96, f, 32 * 4, hipMemcpyHostToDevice, c->stream));
   }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (redoConfig)

@@ -362,10 +362,13 @@ __device__ __forceinline__ void hit_clear(HitRec &h) {
 // at every use.  The compact ray records' decode (vr_trace.hip) reads its four scalars from here in every kernel; the
 // absorbing flat-scene kernel (8 waves per SIMD, 78 spilled SGPRs) also its wall and scene-box frame: the *_lds
 // variants below (C2 trace 6.5 -> 6.3 ms; the general kernels measured 3 % SLOWER with them and keep the arguments).
-constexpr int VR_WALL_TABLE = 120; // floats
+constexpr int VR_WALL_TABLE = 128; // floats
 enum { VR_F_SRC_PLANE = 96, VR_F_RAYDIR = 97, VR_F_FIRSTDIR = 98, VR_F_SECONDDIR = 99, VR_F_EXTRA_LO = 100, VR_F_EXTRA_HI = 101,
        VR_F_LO1 = 102 /* lo1, hi1, lo2, hi2 */, VR_F_WALL_LO_R = 106, VR_F_WALL_HI_R = 107, VR_F_SCENE_LO = 108, VR_F_SCENE_HI = 111,
-       VR_F_PQ_PAD = 114, VR_F_BC0 = 115, VR_F_BC1 = 116, VR_F_NB_DIST = 117 };
+       VR_F_PQ_PAD = 114, VR_F_BC0 = 115, VR_F_BC1 = 116, VR_F_NB_DIST = 117,
+       // the height field over the source plane (HeightFieldParams; NX = 0: none)
+       VR_F_HF_LO1 = 118, VR_F_HF_LO2 = 119, VR_F_HF_INVT = 120, VR_F_HF_TILE = 121, VR_F_HF_TOP = 122, VR_F_HF_SIGN = 123,
+       VR_F_HF_NX = 124, VR_F_HF_NY = 125, VR_F_HF_PTR_LO = 126, VR_F_HF_PTR_HI = 127 };
 
 __device__ __forceinline__ void hit_walls(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
                                           const V3 &d, float tnear, HitRec &h) {

@@ -929,6 +929,69 @@ size_t wide_tree_entries(unsigned n) {
   return total + 1;
 }
 
+// ---------------------------------------------------------------------------
+// height field over the source plane (HeightFieldParams, vr_types.hpp)
+// ---------------------------------------------------------------------------
+__global__ void height_field_kernel(HeightFieldParams q) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= q.n)
+    return;
+  const float4 *pr = reinterpret_cast<const float4 *>(q.prims);
+  float lo[3], hi[3];
+  if (q.geo == 0) {
+    const float4 c = pr[2 * (size_t)i], n = pr[2 * (size_t)i + 1];
+    const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
+    for (int k = 0; k < 3; ++k) { // the disc's own extent along axis k (as the BVH's boxes: vr_setup.hip, box_kernel)
+      const float e = c.w * sqrtf(fmaxf(0.f, 1.f - nn[k] * nn[k])) * 1.0001f;
+      lo[k] = cc[k] - e;
+      hi[k] = cc[k] + e;
+    }
+  } else {
+    const float4 a = pr[4 * (size_t)i], e1 = pr[4 * (size_t)i + 1], e2 = pr[4 * (size_t)i + 2];
+    const float v0[3] = {a.x, a.y, a.z}, v1[3] = {a.x - e1.x, a.y - e1.y, a.z - e1.z}, v2[3] = {a.x + e2.x, a.y + e2.y, a.z + e2.z};
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = fminf(v0[k], fminf(v1[k], v2[k]));
+      hi[k] = fmaxf(v0[k], fmaxf(v1[k], v2[k]));
+    }
+  }
+  const float top = (q.sign > 0.f ? hi[q.ax] : -lo[q.ax]) + q.pad;
+  const int ix0 = min(max((int)floorf((lo[q.a1] - q.pad - q.lo1) * q.invTile), 0), q.nx - 1);
+  const int ix1 = min(max((int)floorf((hi[q.a1] + q.pad - q.lo1) * q.invTile), 0), q.nx - 1);
+  int iy0 = 0, iy1 = 0;
+  if (q.ny > 1) {
+    iy0 = min(max((int)floorf((lo[q.a2] - q.pad - q.lo2) * q.invTile), 0), q.ny - 1);
+    iy1 = min(max((int)floorf((hi[q.a2] + q.pad - q.lo2) * q.invTile), 0), q.ny - 1);
+  }
+  for (int iy = iy0; iy <= iy1; ++iy)
+    for (int ix = ix0; ix <= ix1; ++ix)
+      atomicMax(&q.raw[iy * q.nx + ix], f2ord(top));
+}
+
+__global__ void height_dilate_kernel(HeightFieldParams q) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= q.nx * q.ny)
+    return;
+  const int ix = t % q.nx, iy = t / q.nx;
+  unsigned m = 0u; // (f2ord: 0 is below every float — a tile nothing reaches into)
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int x = ix + dx, y = iy + dy;
+      if (x >= 0 && x < q.nx && y >= 0 && y < q.ny)
+        m = max(m, q.raw[y * q.nx + x]);
+    }
+  q.field[t] = m ? ord2f(m) : -3.0e38f;
+}
+
+hipError_t launch_height_field(const HeightFieldParams &q, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(q.raw, 0, (size_t)q.nx * q.ny * 4, st);
+  if (e != hipSuccess)
+    return e;
+  if (q.n)
+    hipLaunchKernelGGL(height_field_kernel, dim3((q.n + 255) / 256), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(height_dilate_kernel, dim3((q.nx * q.ny + 255) / 256), dim3(256), 0, st, q);
+  return hipGetLastError();
+}
+
 // builds the tree from s.sbox (sorted, padded boxes); out3 = the root's {first child entry,
 // child count | VR_WIDE_PRIMS if the root's children are the primitives themselves, 0}
 hipError_t launch_wide_tree(const SetupParams &s, unsigned *out3, hipStream_t st) {

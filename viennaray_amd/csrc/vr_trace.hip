@@ -1265,6 +1265,71 @@ trace_kernel(const TraceParams p) {
         }
       }
     }
+    if constexpr (!ABSORB && !FOLLOW) {
+      // ---- segments that rise clear (the general kernels without the packet query's candidate list).  A ray that goes
+      // on after this round's event — reflected off the TOP surface of a structure: a fifth of all segments of a trench
+      // — used to keep its lane for one more round: a walk of two or three steps while the other lanes walk thirty.
+      // The height field over the source plane (HeightFieldParams: per tile the highest point of anything in the tile
+      // or its eight neighbours, plus a rounding margin) decides it here: a ray that is above its tile's height from
+      // tnear on, and rises above the whole scene before it has travelled a tile sideways, cannot meet the geometry —
+      // a primitive it met would hold a point of the ray, hence reach up to the ray's height within those nine tiles.
+      // Such a segment is finished in this round: wall test, then the miss / boundary branches of the state machine
+      // (rayTraceKernel.hpp:169-214), and its lane pulls a new ray in the next round.  (Not with a mean free path: that
+      // scatter is drawn before the boundary branch.  VR_DEBUG_FLAGS=256 switches this off; the tests run both ways.)
+      if (!(p.debugFlags & 256u) && !(EXT && EXT_FULL && p.meanFreePath > 0.f)) {
+        bool clear = false;
+        const int hnx = __float_as_int(wallS[VR_F_HF_NX]);
+        if (hnx > 0 && fin && active) {
+          const int ax = __float_as_int(wallS[VR_F_RAYDIR]), a1 = __float_as_int(wallS[VR_F_FIRSTDIR]), a2 = __float_as_int(wallS[VR_F_SECONDDIR]);
+          const float sgn = wallS[VR_F_HF_SIGN];
+          const float up = sgn * getc(dir, ax);
+          if (up > 0.f) {
+            const float hz = sgn * getc(org, ax);
+            const float invT = wallS[VR_F_HF_INVT];
+            const int hny = __float_as_int(wallS[VR_F_HF_NY]);
+            int ix = (int)floorf((getc(org, a1) - wallS[VR_F_HF_LO1]) * invT);
+            ix = ix < 0 ? 0 : (ix >= hnx ? hnx - 1 : ix);
+            int iy = 0;
+            float d2 = 0.f;
+            if (D == 3) {
+              iy = (int)floorf((getc(org, a2) - wallS[VR_F_HF_LO2]) * invT);
+              iy = iy < 0 ? 0 : (iy >= hny ? hny - 1 : iy);
+              d2 = getc(dir, a2);
+            }
+            typedef const __attribute__((address_space(1))) float *GlobalF;
+            const GlobalF field = reinterpret_cast<GlobalF>(((unsigned long long)__float_as_uint(wallS[VR_F_HF_PTR_HI]) << 32) |
+                                                            __float_as_uint(wallS[VR_F_HF_PTR_LO]));
+            const float height = field[iy * hnx + ix];
+            const float d1 = getc(dir, a1);
+            const float tTop = fmaxf(wallS[VR_F_HF_TOP] - hz, 0.f) / up; // where the ray passes the top of the scene box
+            clear = hz + up * tnear > height && tTop * sqrtf(d1 * d1 + d2 * d2) <= 0.99f * wallS[VR_F_HF_TILE];
+          }
+        }
+        if (clear) {
+          HitRec h2;
+          hit_clear(h2);
+          hit_walls(p, wallS, org, dir, tnear, h2);
+          VR_COUNT(K_TRACES, 1);
+          if (h2.geom < 0) { // miss, :172-176
+            VR_COUNT(K_NONGEO, 1);
+            active = false;
+          } else { // boundary, :206-214
+            const V3 hitPoint = mk(org.x + dir.x * h2.t, org.y + dir.y * h2.t, org.z + dir.z * h2.t);
+            if (++boundaryHits > p.maxBoundaryHits) {
+              VR_COUNT(K_TERM, 1);
+              active = false;
+            } else {
+              process_boundary_hit<D>(p, wallS, h2.prim, hitPoint, org, rayDirection, dir, active);
+            }
+          }
+          if (!active) {
+            VR_COUNT(K_BOUNDARY, boundaryHits);
+            VR_COUNT(K_REFL, numReflections);
+          }
+          start = active;
+        }
+      }
+    }
     TICK(6);
   }
 

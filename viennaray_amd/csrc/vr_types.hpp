@@ -149,6 +149,21 @@ struct TraceParams {
   uint32_t numGlobalVec, globalStride, numGlobalScalars;
 };
 
+// Height field over the source plane (vr_setup.hip: height_field_kernel): per tile of side `tile` the highest point —
+// along the source axis, towards the source — of any primitive that reaches into the tile or one of its eight
+// neighbours, plus a rounding margin.  A ray that is above it from tnear on, and rises above the whole scene before it
+// has travelled one tile sideways, cannot meet the geometry (trace_kernel, "segments that rise clear").
+struct HeightFieldParams {
+  const float *prims;   // primitive records (disks: 2 x float4, triangles: 4 x float4)
+  uint32_t n;
+  int32_t geo, ax, a1, a2; // source axis and the two axes of the plane (a2 unused where ny == 1)
+  float sign;           // +1: the source lies on the max side of the source axis
+  float lo1, lo2, invTile, pad;
+  int32_t nx, ny;
+  uint32_t *raw;        // nx * ny ordered-uint maxima (zeroed)
+  float *field;         // nx * ny: the 3 x 3 dilation of raw
+};
+
 // device-side scene setup (vr_setup.hip)
 // Morton grid of the LBVH: the cell is the scene box's proportions, but at most VR_MORTON_ANISO : 1 (see morton_kernel)
 constexpr float VR_MORTON_ANISO = 2.0f;
