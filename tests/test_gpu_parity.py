@@ -680,6 +680,44 @@ def test_follow_up_segments_inside_a_packet_query_round(surface, particle, bcs, 
             assert (t2.getFluxF64() == f0).all(), knobs
 
 
+@pytest.mark.parametrize("direction", [TD.POS_Z, TD.NEG_Z])
+@pytest.mark.parametrize("particle", [("diffuse", 0.2, 1.0), ("specular", 0.3, 1.0)])
+def test_segments_that_rise_clear_respect_nearby_relief(particle, direction, monkeypatch):
+    """The general kernels finish a continuing ray in the round of its reflection when the height field over the source
+    plane says it rises clear of everything near by.  A plane with a dome in its middle: rays reflected off the plane
+    next to the dome DO meet it, rays far from it do not — same counters and flux as the oracle, and the same bits with
+    the shortcut switched off (VR_DEBUG_FLAGS=256).  Source above and (back faces first) below."""
+    n, gd = 90, 0.5
+    ax = (np.arange(n) - (n - 1) / 2.0) * gd
+    x, y = np.meshgrid(ax, ax, indexing="ij")
+    rr = np.sqrt(x * x + y * y)
+    R, H = 8.0, 5.0                      # a paraboloid dome of radius R and height H
+    z = np.where(rr < R, H * (1.0 - (rr / R) ** 2), 0.0)
+    gx = np.where(rr < R, -2.0 * H * x / R ** 2, 0.0)
+    gy = np.where(rr < R, -2.0 * H * y / R ** 2, 0.0)
+    nrm = np.stack([-gx, -gy, np.ones_like(x)], -1).reshape(-1, 3)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pts = np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32)
+    nrm = nrm.astype(np.float32)
+    bcs = [BC.REFLECTIVE_BOUNDARY, BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY]
+
+    def pair():
+        return make_pair_disks(pts, nrm, gd, 3, bcs, direction, particle, rays_pp=60, seed=77)
+
+    t, o = pair()
+    err, info = compare(t, o)
+    assert t.traceMode() == 0
+    if direction == TD.POS_Z:
+        assert info["geometryHits"] > 1.005 * info["numRays"]  # (reflected rays meet the dome)
+    f0 = t.getFluxF64()
+    with monkeypatch.context() as m:
+        m.setenv("VR_DEBUG_FLAGS", "256")
+        t2, _ = pair()
+        t2.apply()
+        assert info_dict(t2) == info
+        assert (t2.getFluxF64() == f0).all()
+
+
 def test_morton_grid_keeps_its_proportions_bounded(monkeypatch):
     """The LBVH's Morton grid follows the scene box's proportions only up to 2 : 1.  Scaled freely axis by axis, a thin
     sheet (here 400 x 400 cells wide, one cell of relief) spends a third of the code bits on its relief and the tree cuts
