@@ -187,6 +187,7 @@ struct vr_context {
   DevBuf<uint32_t> dNormMax;          // flux_max_kernel's reduction word
   bool areasValid = false;
   DevBuf<uint32_t> dNbOff, dNbIds, dLeafOfOrig;
+  DevBuf<uint32_t> dNbTmp; // the one-pass neighbourhood query's fixed-stride lists (build scratch)
   uint32_t nbTotal = 0;               // entries of the resident neighbourhood CSR
   DevBuf<unsigned long long> dFluxAcc, dFluxOrig, dCounters, dScratch;
   DevBuf<unsigned long long> dWorkQ;  // span cursors of the trace kernel's per-XCD queues
@@ -310,6 +311,7 @@ void vr_destroy(vr_context *c) {
   c->dPrims.release();
   c->dPrimSticking.release();
   c->dNbOff.release();
+  c->dNbTmp.release();
   c->dNbIds.release();
   c->dHfRaw.release();
   c->dHf.release();
@@ -908,8 +910,8 @@ static int build_scene(vr_context *c) {
   if (disk) {
     VR_HIP(c, c->dDisk4.ensure((size_t)N * 4));
     VR_HIP(c, c->dPoints3.ensure((size_t)N * 3));
-    VR_HIP(c, hipMemcpyAsync(c->dDisk4.p, g.disk4.data(), (size_t)N * 16, hipMemcpyHostToDevice, c->stream));
     VR_HIP(c, hipMemcpyAsync(c->dPoints3.p, g.points3.data(), (size_t)N * 12, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, launch_disk4(c->dPoints3.p, N, g.diskRadius, g.D, c->dDisk4.p, c->stream)); // (= g.disk4, made on the device)
   } else {
     VR_HIP(c, c->dVerts.ensure(g.verts.size()));
     VR_HIP(c, c->dTris.ensure(g.tris.size()));
@@ -979,17 +981,23 @@ static int build_scene(vr_context *c) {
   c->lastSetup = s;
   c->haveSetup = true;
   if (disk) {
-    // neighbourhood: count -> scan -> fill
+    // neighbourhood: ONE query that counts and keeps up to VR_NB_KEEP ids per primitive -> scan -> pack (the query, a
+    // range walk of the BVH per primitive, is the most expensive kernel of a build: 0.4 ms per 10^6 disks; counting and
+    // filling in two passes walked twice).  A primitive with more neighbours: the two-pass path.
+    VR_HIP(c, c->dNbTmp.ensure((size_t)N * VR_NB_KEEP + 1));
+    s.nbTmp = c->dNbTmp.p;
+    VR_HIP(c, hipMemsetAsync(c->dNbTmp.p + (size_t)N * VR_NB_KEEP, 0, 4, c->stream));
     VR_HIP(c, hipMemsetAsync(c->dNbOff.p + N, 0, 4, c->stream));
-    VR_HIP(c, launch_setup_neighbors(s, 0, c->stream));
+    VR_HIP(c, launch_setup_neighbors(s, 2, c->stream));
     VR_HIP(c, launch_scan(c->dNbOff.p, N + 1, c->dScanTmp.p, c->stream));
-    uint32_t total = 0;
+    uint32_t total = 0, overflow = 0;
     VR_HIP(c, hipMemcpyAsync(&total, c->dNbOff.p + N, 4, hipMemcpyDeviceToHost, c->stream));
+    VR_HIP(c, hipMemcpyAsync(&overflow, c->dNbTmp.p + (size_t)N * VR_NB_KEEP, 4, hipMemcpyDeviceToHost, c->stream));
     VR_HIP(c, hipStreamSynchronize(c->stream));
     VR_HIP(c, c->dNbIds.ensure(total));
     c->nbTotal = total;
     s.nbIds = c->dNbIds.p;
-    VR_HIP(c, launch_setup_neighbors(s, 1, c->stream));
+    VR_HIP(c, launch_setup_neighbors(s, (overflow || std::getenv("VR_NB_TWO_PASS")) ? 1 : 3, c->stream));
   } else {
     c->nbTotal = 0;
     VR_HIP(c, hipMemsetAsync(c->dNbOff.p, 0, ((size_t)N + 1) * 4, c->stream));

@@ -529,7 +529,7 @@ template <int PASS> __global__ void nb_kernel(SetupParams s) {
   const float qlo[3] = {px - dist, py - dist, s.D == 2 ? -FLT_MAX : pz - dist};
   const float qhi[3] = {px + dist, py + dist, s.D == 2 ? FLT_MAX : pz + dist};
   unsigned count = 0;
-  const unsigned base = PASS ? s.nbOff[q] : 0u;
+  const unsigned base = PASS == 1 ? s.nbOff[q] : 0u;
   unsigned node = 0;
   while (node != VR_END) {
     const float4 a = nodes[2 * (size_t)node], b = nodes[2 * (size_t)node + 1];
@@ -548,8 +548,10 @@ template <int PASS> __global__ void nb_kernel(SetupParams s) {
           bool near = fabsf(dx) <= dist && fabsf(dy) <= dist && (s.D == 2 || fabsf(dz) <= dist);
           near = near && ((dx * dx + dy * dy) + dz * dz) <= dist2;
           if (near) {
-            if (PASS)
+            if (PASS == 1)
               s.nbIds[base + count] = r;
+            else if (PASS == 2 && count < VR_NB_KEEP)
+              s.nbTmp[(size_t)q * VR_NB_KEEP + count] = r;
             ++count;
           }
         }
@@ -561,8 +563,21 @@ template <int PASS> __global__ void nb_kernel(SetupParams s) {
       node = esc;
     }
   }
-  if (!PASS)
+  if (PASS != 1)
     s.nbOff[q] = count;
+  if (PASS == 2 && count > VR_NB_KEEP)
+    s.nbTmp[(size_t)s.n * VR_NB_KEEP] = 1u; // (more neighbours than kept: the caller falls back to count + fill)
+}
+
+// pass 2's lists, packed behind the scanned offsets (the query itself — a range walk of the BVH per primitive, the most
+// expensive kernel of a scene build — runs once instead of twice)
+__global__ void nb_compact_kernel(SetupParams s) {
+  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= s.n)
+    return;
+  const unsigned b = s.nbOff[q], e = s.nbOff[q + 1];
+  for (unsigned j = b; j < e; ++j)
+    s.nbIds[j] = s.nbTmp[(size_t)q * VR_NB_KEEP + (j - b)];
 }
 
 // ---------------------------------------------------------------------------
@@ -929,6 +944,19 @@ size_t wide_tree_entries(unsigned n) {
   return total + 1;
 }
 
+// the discs' {centre, radius} records from the caller's points (one radius for all: rayGeometryDisk.hpp:60-75; 2-D: the z
+// column is ignored) — 16 bytes per disk that need not cross PCIe
+__global__ void disk4_kernel(const float *points3, unsigned n, float radius, int D, float4 *disk4) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    disk4[i] = make_float4(points3[3 * (size_t)i], points3[3 * (size_t)i + 1], D == 2 ? 0.f : points3[3 * (size_t)i + 2], radius);
+}
+hipError_t launch_disk4(const float *points3, unsigned n, float radius, int D, float *disk4, hipStream_t st) {
+  if (n)
+    hipLaunchKernelGGL(disk4_kernel, dim3((n + 255) / 256), dim3(256), 0, st, points3, n, radius, D, reinterpret_cast<float4 *>(disk4));
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // height field over the source plane (HeightFieldParams, vr_types.hpp)
 // ---------------------------------------------------------------------------
@@ -1045,8 +1073,12 @@ hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st
     return hipSuccess;
   if (pass == 0)
     hipLaunchKernelGGL((nb_kernel<0>), dim3(g), dim3(256), 0, st, s);
-  else
+  else if (pass == 1)
     hipLaunchKernelGGL((nb_kernel<1>), dim3(g), dim3(256), 0, st, s);
+  else if (pass == 2) // count and keep (s.nbTmp; its overflow word zeroed by the caller)
+    hipLaunchKernelGGL((nb_kernel<2>), dim3(g), dim3(256), 0, st, s);
+  else                // pack pass 2's lists behind the scanned offsets
+    hipLaunchKernelGGL(nb_compact_kernel, dim3(g), dim3(256), 0, st, s);
   return hipGetLastError();
 }
 

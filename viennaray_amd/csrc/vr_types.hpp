@@ -167,6 +167,7 @@ struct HeightFieldParams {
 // device-side scene setup (vr_setup.hip)
 // Morton grid of the LBVH: the cell is the scene box's proportions, but at most VR_MORTON_ANISO : 1 (see morton_kernel)
 constexpr float VR_MORTON_ANISO = 2.0f;
+constexpr unsigned VR_NB_KEEP = 24; // ids the one-pass neighbourhood query keeps per primitive (more: the two-pass path)
 struct SetupParams {
   // inputs (device copies of the caller's arrays)
   const float *disk4;     // n x {x,y,z,r}
@@ -195,6 +196,7 @@ struct SetupParams {
   float *prims;
   uint32_t *leafOfOrig, *order;
   uint32_t *nbOff, *nbIds;
+  uint32_t *nbTmp;        // pass 2 (count AND keep): VR_NB_KEEP ids per primitive; nbTmp[n * VR_NB_KEEP] = overflow flag
   float *wide;            // 64-ary box tree (see TraceParams::wide), (n + n/64 + ...) x 8 floats
   float mortonAniso;      // cells of the Morton grid: at most this much finer along an axis than along the longest one
 };
