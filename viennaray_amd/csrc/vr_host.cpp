@@ -71,7 +71,7 @@ void host_set_disks(HostGeometry &g, const float *pts, const float *nrm, uint32_
   g.diskRadius = radius > 0.f ? radius : (float)(gridDelta * factor);
   g.disk4.resize((size_t)n * 4);
   g.normal3.resize((size_t)n * 3);
-  g.points3.assign(pts, pts + (size_t)n * 3);
+  g.points3.resize((size_t)n * 3); // (filled by the threads below: a serial copy of 12 MB was half of this function)
   for (int k = 0; k < D; ++k) {
     g.minC[k] = std::numeric_limits<float>::max();
     g.maxC[k] = std::numeric_limits<float>::lowest();
@@ -93,8 +93,9 @@ void host_set_disks(HostGeometry &g, const float *pts, const float *nrm, uint32_
       d[1] = p[1];
       d[2] = D == 2 ? 0.f : p[2];
       d[3] = g.diskRadius;
-      if (D == 2)
-        g.points3[3 * (size_t)i + 2] = 0.f; // (2-D: the z column is ignored, rayGeometryDisk.hpp:148-151)
+      g.points3[3 * (size_t)i] = p[0];
+      g.points3[3 * (size_t)i + 1] = p[1];
+      g.points3[3 * (size_t)i + 2] = D == 2 ? 0.f : p[2]; // (2-D: the z column is ignored, rayGeometryDisk.hpp:148-151)
       for (int k = 0; k < D; ++k) { // (thread-local: the shared arrays would ping-pong between cores)
         lmin[k] = std::min(lmin[k], p[k]);
         lmax[k] = std::max(lmax[k], p[k]);
