@@ -1283,6 +1283,65 @@ def test_c2_full_size_properties():
         assert parts[0][1][k] + parts[1][1][k] == i[k], k
 
 
+@pytest.mark.parametrize("config", ["C1_trench3d", "C4", "C5"])
+def test_structured_configs_full_size_properties(config, monkeypatch):
+    """The structured BASELINE configs at their FULL ray counts (no oracle in the suite at this size: tools/
+    full_parity_case.py did that once per build, profiles/r03_full_parity_cases.txt): segment conservation, a bit-identical
+    rerun, two ray-range shards summing bit-exactly to the whole — and the same counters and accumulator bits with the
+    height-field and follow-up shortcuts switched off (VR_DEBUG_FLAGS=256)."""
+    def tracer():
+        if config == "C4":
+            gd, v, tri = trench_mesh()
+            t = vr.TraceTriangle(3)
+            t.setGeometry(v, tri, gd)
+            t.setParticleType(vr.SpecularParticle(0.1, 50.0, "flux"))
+            t.setNumberOfRaysFixed(100_000_000)
+        elif config == "C5":
+            gd, p, n = trench2d()
+            t = vr.TraceDisk(2)
+            t.setGeometry(p, n, gd)
+            t.setSourceDirection(TD.POS_Y)
+            t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 2)
+            t.setParticleType(vr.DiffuseParticle(0.1, "flux"))
+            t.setNumberOfRaysFixed(100_000_000)
+        else:
+            gd, p, n = trench3d()
+            t = vr.TraceDisk(3)
+            t.setGeometry(p, n, gd)
+            t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+            t.setParticleType(vr.DiffuseParticle(0.1, "flux"))
+            t.setNumberOfRaysPerPoint(2000)   # the reference example's 5.78e7 rays
+        t.setRngSeed(12345)
+        return t
+
+    t = tracer()
+    t.apply()
+    i = info_dict(t)
+    whole = t.getFluxF64()
+    rays = i["numRays"]
+    assert rays >= 50_000_000
+    # every trace ends on the geometry, on a wall (and goes on) or leaves; every ray ends exactly once
+    assert i["totalRaysTraced"] >= i["geometryHits"] + i["nonGeometryHits"] + i["boundaryHits"]  # (+ back-face passes)
+    assert i["reflections"] > rays and whole.sum() > 0
+    t.setRunNumber(1)
+    t.apply()
+    assert (t.getFluxF64() == whole).all() and info_dict(t) == i
+    half = rays // 2
+    parts = []
+    for first, count in ((0, half), (half, rays - half)):
+        t.setRunNumber(1)
+        t.setRayRange(first, count)
+        t.apply()
+        parts.append((t.getFluxF64(), info_dict(t)))
+    assert (parts[0][0] + parts[1][0] == whole).all()
+    for k in INFO_KEYS[1:]:
+        assert parts[0][1][k] + parts[1][1][k] == i[k], k
+    monkeypatch.setenv("VR_DEBUG_FLAGS", "256")
+    t2 = tracer()
+    t2.apply()
+    assert info_dict(t2) == i and (t2.getFluxF64() == whole).all()
+
+
 # ---------------------------------------------------------------------------
 # BASELINE config C3: the same plane, 10^9 rays in total, index range sharded over 8 GPUs (SURVEY 8e:
 # GPU g traces idx in [g * 1.25e8, (g + 1) * 1.25e8); global idx -> tea<3>(idx, seed), rayTraceKernel.hpp:118-121)
