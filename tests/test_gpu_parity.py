@@ -680,6 +680,137 @@ def test_follow_up_segments_inside_a_packet_query_round(surface, particle, bcs, 
             assert (t2.getFluxF64() == f0).all(), knobs
 
 
+def _relief_surface(kind, n=140, gd=0.5):
+    """Sheets of disks that are flat WITH RELIEF (a few grid cells thick at most): the rippled sheet, a plane with one
+    bump a third of a cell high, terraces (steps of 1.5 cells, no risers: the rays see both levels' rims), a tilted sheet."""
+    if kind == "ripple":
+        return _rippled_surface(n=n, gd=gd, amp=0.5 * gd / 0.5, wave=2.0)
+    ax = (np.arange(n) - (n - 1) / 2.0) * gd
+    x, y = np.meshgrid(ax, ax, indexing="ij")
+    if kind == "bump":
+        rr2 = (x * x + y * y) / (6.0 * gd) ** 2
+        z = 0.3 * gd * np.exp(-rr2)
+        gx, gy = -2.0 * x / (6.0 * gd) ** 2 * z, -2.0 * y / (6.0 * gd) ** 2 * z
+    elif kind == "steps":
+        z = 1.5 * gd * (np.floor((x - ax[0]) / (9.0 * gd)) % 2)
+        gx = gy = np.zeros_like(x)
+    else:  # "tilt": a plane tilted by 2 cells over the sheet's width (its normal not along the source axis)
+        slope = 2.0 * gd / (n * gd)
+        z = slope * x
+        gx, gy = np.full_like(x, slope), np.zeros_like(x)
+    nrm = np.stack([-gx, -gy, np.ones_like(x)], -1).reshape(-1, 3)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return np.stack([x, y, z], -1).reshape(-1, 3).astype(np.float32), nrm.astype(np.float32), gd
+
+
+RELIEF_KNOBS = [
+    {"VR_DEBUG_FLAGS": "512"},     # the packet query clips to the scene box again (grazing rays still filed apart)
+    {"VR_NO_RELIEF": "1"},         # the kernels for structured scenes, one set of bins
+    {"VR_RELIEF_TRAVEL": "0.2"},   # nearly every ray is filed as loose
+    {"VR_RELIEF_TRAVEL": "50"},    # ... none is
+    {"VR_RELIEF_TILE": "0.5"}, {"VR_RELIEF_TILE": "3"},
+    {"VR_RELIEF_LOOKUPS": "2"}, {"VR_RELIEF_LOOKUPS": "0"}, {"VR_RELIEF_COARSE_K": "1"},
+    {"VR_RAYS_PER_BIN": "3"}, {"VR_BATCH_RAYS": "50000"},
+    {"VR_BIN_CAP": "8", "VR_RAYS_PER_BIN": "16"},  # most rays overflow their (tight or loose) bin
+]
+
+
+@pytest.mark.parametrize("particle", [("diffuse", 1.0, 1.0), ("diffuse", 0.1, 1.0), ("specular", 0.2, 30.0)])
+@pytest.mark.parametrize("surface", ["ripple", "bump", "steps", "tilt"])
+def test_relief_packets_match_the_oracle(surface, particle, monkeypatch):
+    """Scenes that are flat with relief run the flat-scene kernels with the packet query clipped to the LOCAL relief
+    (MODE 5 absorbing / 6 general): rays sorted by their predicted first hit, grazing rays filed in loose bins that the
+    structured-scene kernel traces.  Counters equal and flux as the oracle's on four kinds of relief; the same accumulator
+    bits with the clip, the relief path, the loose bins or the field's resolution changed (every knob only re-orders work
+    or loosens a conservative bound)."""
+    pts, nrm, gd = _relief_surface(surface)
+    bcs = [BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY, BC.REFLECTIVE_BOUNDARY]
+
+    def pair():
+        return make_pair_disks(pts, nrm, gd, 3, bcs, TD.POS_Z, particle, rays_pp=40, seed=4242)
+
+    t, o = pair()
+    err, info = compare(t, o, exact_flux=particle[1] >= 1.0)
+    assert t.traceMode() == (5 if particle[1] >= 1.0 else 6), t.traceMode()
+    assert info["boundaryHits"] > 0
+    f0 = t.getFluxF64()
+    for knobs in RELIEF_KNOBS:
+        with monkeypatch.context() as m:
+            for k, v in knobs.items():
+                m.setenv(k, v)
+            t2, _ = pair()
+            t2.apply()
+            assert info_dict(t2) == info, knobs
+            assert (t2.getFluxF64() == f0).all(), knobs
+            if "VR_NO_RELIEF" in knobs:
+                assert t2.traceMode() in (0, 2)
+
+
+@pytest.mark.parametrize("direction", [TD.NEG_Z, TD.POS_X])
+def test_relief_packets_other_source_sides(direction):
+    """The relief field lives over the SOURCE plane: source below the sheet (back faces first), and a sheet seen from +x."""
+    pts, nrm, gd = _relief_surface("ripple", n=120)
+    if direction == TD.POS_X:  # the same sheet stood up: its height along x
+        pts = np.ascontiguousarray(pts[:, [2, 0, 1]])
+        nrm = np.ascontiguousarray(nrm[:, [2, 0, 1]])
+    for particle in (("diffuse", 1.0, 1.0), ("diffuse", 0.3, 1.0)):
+        t, o = make_pair_disks(pts, nrm, gd, 3, [BC.REFLECTIVE_BOUNDARY] * 3, direction, particle, rays_pp=30, seed=7)
+        compare(t, o)
+        assert t.traceMode() in (5, 6)
+
+
+def test_relief_packets_2d_and_triangles():
+    """D = 2 (a rippled line of disks too long for the LDS-resident kernel: the relief field is one row of tiles) and an
+    absorbing particle on a rippled triangle mesh (the absorbing relief kernel serves triangles too)."""
+    n, gd = 4000, 0.5
+    x = (np.arange(n) - (n - 1) / 2.0) * gd
+    y = 0.2 * np.sin(x / 2.0)
+    nrm = np.stack([-0.1 * np.cos(x / 2.0), np.ones_like(x), np.zeros_like(x)], -1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pts = np.stack([x, y, np.zeros_like(x)], -1).astype(np.float32)
+    for particle in (("diffuse", 1.0, 1.0), ("diffuse", 0.2, 1.0)):
+        t, o = make_pair_disks(pts, nrm.astype(np.float32), gd, 2, [BC.PERIODIC_BOUNDARY] * 2, TD.POS_Y, particle, rays_pp=300, seed=11)
+        compare(t, o)
+        assert t.traceMode() in (5, 6), t.traceMode()
+    # triangles
+    m, gd = 90, 0.5
+    ax = (np.arange(m) - (m - 1) / 2.0) * gd
+    xx, yy = np.meshgrid(ax, ax, indexing="ij")
+    zz = 0.5 * np.sin(xx / 2.0) * np.cos(yy / 2.0)
+    verts = np.stack([xx, yy, zz], -1).reshape(-1, 3).astype(np.float32)
+    idx = np.arange(m * m).reshape(m, m)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    tris = np.concatenate([np.stack([a, b, c], -1), np.stack([a, c, d], -1)]).astype(np.uint32)
+    t = vr.TraceTriangle(3)
+    t.setGeometry(verts, tris, gd)
+    t.setBoundaryConditions([BC.REFLECTIVE_BOUNDARY] * 3)
+    t.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+    t.setNumberOfRaysPerPoint(30)
+    t.setRngSeed(3)
+    o = po.Oracle()
+    o.set_triangles(verts, tris, gd, 3)
+    o.set_boundary_conditions([po.REFLECTIVE] * 3)
+    o.set_particle(po.DIFFUSE, 1.0)
+    o.set_num_rays_per_point(30)
+    o.set_rng_seed(3)
+    o.set_lazy_rng(True)
+    compare(t, o, exact_flux=True)
+    assert t.traceMode() == 5
+
+
+def test_relief_is_for_thin_scenes_only():
+    """A trench is not "flat with relief": its scene box is sixty cells deep — the general kernels as before."""
+    gd, p, n = trench3d()
+    for sticking, mode in ((1.0, 2), (0.2, 0)):
+        t = vr.TraceDisk(3)
+        t.setGeometry(p, n, gd)
+        t.setParticleType(vr.DiffuseParticle(sticking, "flux"))
+        t.setNumberOfRaysPerPoint(2)
+        t.setRngSeed(1)
+        t.apply()
+        assert t.traceMode() == mode
+
+
 @pytest.mark.parametrize("direction", [TD.POS_Z, TD.NEG_Z])
 @pytest.mark.parametrize("particle", [("diffuse", 0.2, 1.0), ("specular", 0.3, 1.0)])
 def test_segments_that_rise_clear_respect_nearby_relief(particle, direction, monkeypatch):
@@ -740,6 +871,7 @@ def test_morton_grid_keeps_its_proportions_bounded(monkeypatch):
             best = k if best is None else min(best, k)
         return t.getFluxF64(), info_dict(t), best
 
+    monkeypatch.setenv("VR_NO_RELIEF", "1")  # (the walks the Morton grid is about: not the relief packets' flat-scene kernels)
     f0, i0, t0 = run()
     monkeypatch.setenv("VR_MORTON_ANISO", "1000000")
     f1, i1, t1 = run()

@@ -98,6 +98,9 @@ struct ParticleLaunch {
   uint32_t numData = 1, dataBase = 0;
   hipFunction_t userKernel = nullptr; // the trace kernel of a run-time model (nullptr: a kernel of the library)
   float *primSticking = nullptr; // owned (hipMalloc): this particle's per-primitive sticking, leaf order
+  bool relief = false;           // a second launch (looseMode) traces the loose bins
+  int looseMode = 0;
+  unsigned looseGrid = 0;
   vr_trace_info info{};
 };
 
@@ -230,7 +233,18 @@ struct vr_context {
   uint32_t numBins = 0;
   uint64_t rayFirstLaunch = 0, rayEndLaunch = 0;
   bool absorb = true;
-  float frameHost[32] = {0};  // the scalar frame behind the wall table (staging buffer of its upload)
+  float wallsHost[96] = {0};        // the eight wall triangles (made with the bounding box)
+  std::vector<float> frameHostAll;  // wall table + scalar frame of every particle of the apply (staging of their uploads)
+  // relief field over the source plane (ReliefParams): scenes that are flat with relief
+  DevBuf<uint32_t> dRfRawLo, dRfRawHi, dRfStats;
+  DevBuf<float> dRfFine, dRfCoarse;
+  ReliefParams rf{};
+  uint32_t rfBuild = 0xFFFFFFFFu;
+  int rfAxes[4] = {-1, -1, -1, -1};
+  float rfLooseShare = 1.f;
+  bool reliefScene = false;    // the prepared launch: MODE 5 / 6 over the tight bins + looseMode over the loose ones
+  int looseMode = 0;
+  unsigned looseGrid = 0;
   DevBuf<uint32_t> dHfRaw;    // height field over the source plane (HeightFieldParams): built for particles that reflect
   DevBuf<float> dHf;
   HeightFieldParams hf{};
@@ -263,6 +277,7 @@ static int fail(vr_context *c, int code, const char *msg) {
 }
 
 static void size_bins(int D, uint64_t count, uint32_t perBin, TraceParams &p, uint32_t &numBins);
+static void size_loose(int D, TraceParams &p);
 
 extern "C" {
 
@@ -1102,15 +1117,13 @@ static int prepare_one(vr_context *c) {
     {
       Tri walls[8];
       host_build_walls(c->bbLo, c->bbHi, c->ts[1], c->ts[2], walls);
-      float tbl[96];
+      float *tbl = c->wallsHost; // (uploaded with the launch's scalar frame: end of this function)
       for (int i = 0; i < 8; ++i) {
         std::memcpy(tbl + 12 * i, walls[i].v0, 12);
         std::memcpy(tbl + 12 * i + 3, walls[i].e1, 12);
         std::memcpy(tbl + 12 * i + 6, walls[i].e2, 12);
         std::memcpy(tbl + 12 * i + 9, walls[i].Ng, 12);
       }
-      VR_HIP(c, c->dWalls.ensure(VR_WALL_TABLE)); // (the launch's scalar frame behind the walls: end of this function)
-      VR_HIP(c, hipMemcpy(c->dWalls.p, tbl, sizeof(tbl), hipMemcpyHostToDevice));
     }
     // rayBoundary.hpp:23-25: conditions are picked by AXIS
     c->boundaryConds[0] = c->bcs[c->ts[1]];
@@ -1280,6 +1293,94 @@ static int prepare_one(vr_context *c) {
     if (smallScene)
       c->absorb = false; // (ray records with the RNG cursors: the general kernel reads them)
   }
+  // ---- flat WITH RELIEF?  (DESIGN.md 5.2 "relief packets")  The flat-scene kernels owe their speed to the packet
+  // query, and the query clips its rays to the SCENE box: half a grid cell of relief lets the grazing rays of a wave
+  // stretch its box over hundreds of cells.  Where the scene is thin along the source axis and the relief field says that
+  // few rays would be grazing ones (ReliefParams::stats), the rays are sorted by their predicted first hit, the grazing ones are filed apart
+  // (bin_of_relief, vr_trace.hip) and the query clips to the LOCAL relief (relief_clip, vr_device.hpp): MODE 5 / 6.
+  const bool flatScene = c->keyShare >= 0.95f && (c->sceneHi[c->ts[0]] - c->sceneLo[c->ts[0]]) <= 0.25f * c->geo.gridDelta;
+  c->reliefScene = false;
+  {
+    float maxThick = 8.f, travel = 1.5f;
+    if (const char *e = std::getenv("VR_RELIEF_MAX_THICK"))
+      maxThick = (float)std::atof(e);
+    if (const char *e = std::getenv("VR_RELIEF_TRAVEL"))
+      travel = std::max(0.05f, (float)std::atof(e));
+    const float thickScene = c->sceneHi[c->ts[0]] - c->sceneLo[c->ts[0]];
+    const bool plainSource = !c->usePrimaryDirection && c->gridPoints.empty() && c->hostOrg.empty();
+    const bool kernelOk = c->absorb || (c->geo.geo == 0 && c->kernelParticle <= (int)P_EXT);
+    bool want = !flatScene && !smallScene && plainSource && kernelOk && c->userModel < 0 && c->geo.gridDelta > 0.f &&
+                thickScene <= maxThick * c->geo.gridDelta && !std::getenv("VR_NO_RELIEF");
+    if (want) {
+      const bool stale = c->rfBuild != c->bvhBuilds || c->rfAxes[0] != c->ts[0] || c->rfAxes[1] != c->ts[1] ||
+                         c->rfAxes[2] != c->ts[2] || c->rfAxes[3] != c->ts[3] || c->rf.travel != travel * c->geo.gridDelta;
+      if (stale) {
+        ReliefParams &q = c->rf;
+        q.prims = c->dPrims.p;
+        q.n = N;
+        q.geo = c->geo.geo;
+        q.ax = c->ts[0];
+        q.a1 = c->ts[1];
+        q.a2 = c->ts[2];
+        const float ext1 = c->sceneHi[q.a1] - c->sceneLo[q.a1], ext2 = D == 3 ? c->sceneHi[q.a2] - c->sceneLo[q.a2] : 0.f;
+        float cells = 1.f; // fine tile side in grid cells
+        if (const char *e = std::getenv("VR_RELIEF_TILE"))
+          cells = std::max(0.25f, (float)std::atof(e));
+        float tile = std::max(cells * c->geo.gridDelta, std::max(ext1, ext2) / 1024.f);
+        q.tile = tile;
+        q.invTile = 1.f / tile;
+        q.lo1 = c->sceneLo[q.a1];
+        q.lo2 = D == 3 ? c->sceneLo[q.a2] : 0.f;
+        q.nx = std::max(1, std::min(1024, (int)std::ceil(ext1 / tile)));
+        q.ny = D == 3 ? std::max(1, std::min(1024, (int)std::ceil(ext2 / tile))) : 1;
+        q.k = std::max(2, (std::max(q.nx, q.ny) + 255) / 256);
+        if (const char *e = std::getenv("VR_RELIEF_COARSE_K"))
+          q.k = std::max(1, std::atoi(e));
+        q.cnx = (q.nx + q.k - 1) / q.k;
+        q.cny = (q.ny + q.k - 1) / q.k;
+        float scale = 1e-3f;
+        for (int k = 0; k < 3; ++k)
+          scale = std::max(scale, std::max(std::fabs(c->sceneLo[k]), std::fabs(c->sceneHi[k])));
+        q.pad = 1e-5f * scale;
+        q.travel = travel * c->geo.gridDelta;
+        q.emptyMid = c->keyCoord;
+        VR_HIP(c, c->dRfRawLo.ensure((size_t)q.nx * q.ny));
+        VR_HIP(c, c->dRfRawHi.ensure((size_t)q.nx * q.ny));
+        VR_HIP(c, c->dRfFine.ensure((size_t)q.nx * q.ny * 2));
+        VR_HIP(c, c->dRfCoarse.ensure((size_t)q.cnx * q.cny * 2));
+        VR_HIP(c, c->dRfStats.ensure(2));
+        q.rawLo = c->dRfRawLo.p;
+        q.rawHi = c->dRfRawHi.p;
+        q.fine = c->dRfFine.p;
+        q.coarse = c->dRfCoarse.p;
+        q.stats = c->dRfStats.p;
+        VR_HIP(c, launch_relief_field(q, c->stream));
+        uint32_t st[2] = {0, 0};
+        VR_HIP(c, hipMemcpyAsync(st, q.stats, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+        VR_HIP(c, hipStreamSynchronize(c->stream));
+        c->rfLooseShare = st[0] ? (float)st[1] / 4096.f / (float)st[0] : 1.f;
+        c->rfBuild = c->bvhBuilds;
+        for (int k = 0; k < 4; ++k)
+          c->rfAxes[k] = c->ts[k];
+      }
+      // (the share of a cosine source's rays that the generator would file as loose, from the coarse tiles' thickness:
+      //  where most rays are loose the structured-scene kernels do the work anyway, without the second launch)
+      float share = 0.3f;
+      if (const char *e = std::getenv("VR_RELIEF_SHARE"))
+        share = (float)std::atof(e);
+      c->reliefScene = c->rfLooseShare <= share;
+    }
+    p.reliefCoarse = c->reliefScene ? c->rf.coarse : nullptr;
+    p.rcLo1 = c->rf.lo1;
+    p.rcLo2 = c->rf.lo2;
+    p.rcInvT = c->reliefScene ? c->rf.invTile / (float)c->rf.k : 0.f;
+    p.rcNx = c->rf.cnx;
+    p.rcNy = c->rf.cny;
+    p.reliefTravel = travel * c->geo.gridDelta;
+    p.reliefLookups = 1; // (2: tight launch -0.1 ms, generator +0.4 ms per 1e8 rays — a random 8-byte gather per ray is a 128-byte line from L2)
+    if (const char *e = std::getenv("VR_RELIEF_LOOKUPS"))
+      p.reliefLookups = std::min(2, std::max(0, std::atoi(e)));
+  }
   // accumulators: one plane per data label, each replicated accReplicas times
   if (c->accPlanes != c->totalData) {
     VR_HIP(c, c->dFluxAcc.ensure((size_t)c->accStride * c->accReplicas * c->totalData));
@@ -1334,7 +1435,18 @@ static int prepare_one(vr_context *c) {
     uint32_t nb;
     size_bins(D, cap, perBin, p, nb);
     c->numBins = nb;
-    const size_t slots = (size_t)nb * binCap + cap; // bins + overflow region
+    size_t slots = (size_t)nb * binCap + cap; // bins + overflow region
+    size_t cntWords = (size_t)nb + 1;
+    if (c->reliefScene) { // the loose bins with an overflow region of their own, behind the tight ones (size_loose)
+      TraceParams q = p;
+      q.numBins = nb;
+      q.ovCap = cap;
+      size_loose(D, q);
+      slots = (size_t)q.looseSlotBase + (size_t)q.looseNumBins * binCap + cap;
+      cntWords = (size_t)q.looseCntBase + q.looseNumBins + 1;
+      if (slots >= (1ull << 32))
+        return fail(c, VR_E_STATE, "ray stream too large for 32-bit record slots (relief bins)");
+    }
     c->slotStride = slots;
     // 32-byte records for every particle (vr_types.hpp); a non-absorbing particle under a source whose origin plane or
     // draw count varies (tilted, grid, host rays) adds 16 bytes per ray in a side array
@@ -1342,14 +1454,22 @@ static int prepare_one(vr_context *c) {
     const size_t recFloats = 8;
     if (c->recExtra)
       VR_HIP(c, c->dRecExtra.ensure_grow((size_t)cap * 4));
-    size_t slotsWant = slots, binsWant = (size_t)nb + 1;
+    size_t slotsWant = slots, binsWant = cntWords;
     if (c->reserveRays > span) { // vr_reserve_rays: room for the largest apply() announced
       TraceParams q = p;
       uint32_t nbR = 0;
       const uint32_t capR = (uint32_t)std::min<uint64_t>(c->reserveRays, 1ull << 27);
       size_bins(D, capR, perBin, q, nbR);
-      slotsWant = std::max(slotsWant, (size_t)nbR * binCap + capR);
-      binsWant = std::max(binsWant, (size_t)nbR + 1);
+      size_t sR = (size_t)nbR * binCap + capR, bR = (size_t)nbR + 1;
+      if (c->reliefScene) {
+        q.numBins = nbR;
+        q.ovCap = capR;
+        size_loose(D, q);
+        sR = (size_t)q.looseSlotBase + (size_t)q.looseNumBins * binCap + capR;
+        bR = (size_t)q.looseCntBase + q.looseNumBins + 1;
+      }
+      slotsWant = std::max(slotsWant, sR);
+      binsWant = std::max(binsWant, bR);
     }
     VR_HIP(c, c->dSlotRec.ensure_grow(slotsWant * recFloats));
     VR_HIP(c, c->dBinCount.ensure_grow(binsWant));
@@ -1367,9 +1487,11 @@ static int prepare_one(vr_context *c) {
     // grazing rays of a wave stretch its query over dozens of primitives (a 10^6-disk plane with ONE 50 x 50 bump of
     // 0.3 cells: the absorbing kernel 6.4 -> 8.3 ms, the general one 11 -> 18; the kernels for structured scenes are
     // then 2 - 6 % ahead of the flat ones.  DESIGN.md section 10: a flat layer + relief decomposition would close this)
-    const bool flatScene = c->keyShare >= 0.95f && (c->sceneHi[c->ts[0]] - c->sceneLo[c->ts[0]]) <= 0.25f * c->geo.gridDelta;
     c->traceMode = !c->absorb ? ((flatScene && c->geo.geo == 0 && c->kernelParticle <= (int)P_EXT) ? 3 : 0)
                               : (flatScene ? 1 : 2);
+    c->looseMode = c->traceMode;
+    if (c->reliefScene) // flat with relief: the flat-scene kernels on the tight bins, the structured-scene ones on the loose
+      c->traceMode = c->absorb ? 5 : 6;
     if (const char *e = std::getenv("VR_GENERAL_FLAT"))
       if (!c->absorb && c->geo.geo == 0 && c->kernelParticle <= (int)P_EXT)
         c->traceMode = std::atoi(e) ? 3 : 0;
@@ -1378,6 +1500,10 @@ static int prepare_one(vr_context *c) {
         c->traceMode = std::atoi(e) ? 2 : 1;
     if (smallScene)
       c->traceMode = 4;
+    if (c->traceMode != 5 && c->traceMode != 6) { // (an environment switch above took the mode back)
+      c->reliefScene = false;
+      p.reliefCoarse = nullptr;
+    }
     int blocks = 1;
     c->userKernel = nullptr;
     if (c->userModel >= 0) { // the kernel of the model's own code object
@@ -1401,6 +1527,12 @@ static int prepare_one(vr_context *c) {
     if (const char *e = std::getenv("VR_TRACE_BLOCKS"))
       blocks = std::max(1, std::atoi(e));
     c->grid = (unsigned)c->numCUs * (unsigned)blocks;
+    c->looseGrid = 0;
+    if (c->reliefScene) { // (the loose bins hold about a tenth of the rays)
+      int lb = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->kernelParticle, c->looseMode, 0));
+      lb = std::min(lb, std::max(1, (int)std::lround(std::sqrt((double)cap / 1e6))));
+      c->looseGrid = (unsigned)c->numCUs * (unsigned)lb;
+    }
   }
   // deep part of the per-lane walk's stack (entries beyond the LDS-resident ones), one slab per resident wave
   {
@@ -1415,7 +1547,7 @@ static int prepare_one(vr_context *c) {
   {
     size_t waves = 0;
     if (!c->absorb)
-      waves = (size_t)c->grid * (VR_BLOCK / 64);
+      waves = (size_t)std::max(c->grid, c->looseGrid) * (VR_BLOCK / 64);
     if (c->usePrimaryDirection || !c->hostOrg.empty())
       waves = std::max(waves, (size_t)c->numCUs * 8u * (VR_BLOCK / 64)); // launch_gen's grid bound
     if (waves > c->scratchWaves) {
@@ -1458,7 +1590,14 @@ static int prepare_one(vr_context *c) {
   p.nbOff = c->dNbOff.p;
   p.nbIds = c->dNbIds.p;
   p.primSticking = dStick;
-  p.wallTable = c->dWalls.p;
+  { // wall table + scalar frame: one slot per particle of the apply (each kernel stages its own launch's frame in LDS)
+    const size_t nSlots = std::max<size_t>(1, c->specs.size());
+    if (c->dWalls.cap < nSlots * VR_WALL_TABLE)
+      VR_HIP(c, c->dWalls.ensure(nSlots * VR_WALL_TABLE));
+    if (c->frameHostAll.size() < nSlots * VR_WALL_TABLE)
+      c->frameHostAll.assign(nSlots * VR_WALL_TABLE, 0.f);
+  }
+  p.wallTable = c->dWalls.p + (size_t)c->counterSlot * VR_WALL_TABLE;
   p.planeStride = c->accStride * c->accReplicas;
   p.fluxAcc = c->dFluxAcc.p + (size_t)c->dataBase * p.planeStride; // (this particle's planes)
   p.accStride = c->accStride;
@@ -1550,7 +1689,9 @@ static int prepare_one(vr_context *c) {
   if (const char *e = std::getenv("VR_DEBUG_FLAGS"))
     p.debugFlags = (uint32_t)std::atoi(e);
   { // the launch's scalar frame, staged in LDS by the trace kernels (VR_F_*, vr_device.hpp)
-    float *f = c->frameHost;
+    float *const slotHost = c->frameHostAll.data() + (size_t)c->counterSlot * VR_WALL_TABLE;
+    std::memcpy(slotHost, c->wallsHost, sizeof(c->wallsHost));
+    float *f = slotHost + 96;
     auto bits = [](int32_t v) {
       float r;
       std::memcpy(&r, &v, 4);
@@ -1575,8 +1716,20 @@ static int prepare_one(vr_context *c) {
     f[19] = bits(p.bc0);
     f[20] = bits(p.bc1);
     f[21] = p.nbDist;
-    for (int k = 22; k < 32; ++k)
+    for (int k = 22; k < VR_WALL_TABLE - 96; ++k)
       f[k] = 0.f;
+    if (c->reliefScene) { // the relief field's fine tiles (VR_F_RF_*: relief_clip, vr_device.hpp)
+      const ReliefParams &q = c->rf;
+      f[32] = q.lo1;
+      f[33] = q.lo2;
+      f[34] = q.invTile;
+      f[35] = q.tile;
+      f[36] = bits(q.nx);
+      f[37] = bits(q.ny);
+      const uint64_t addr = (uint64_t)(uintptr_t)q.fine;
+      f[38] = bits((int32_t)(uint32_t)(addr & 0xFFFFFFFFull));
+      f[39] = bits((int32_t)(uint32_t)(addr >> 32));
+    }
     // height field over the source plane: for particles that go on after a hit ("segments that rise clear", vr_trace.hip)
     if (!c->absorb && c->geo.numPrims && !std::getenv("VR_NO_HEIGHT_FIELD")) {
       const bool stale = c->hfBuild != c->bvhBuilds || c->hfAxes[0] != c->ts[0] || c->hfAxes[1] != c->ts[1] ||
@@ -1628,7 +1781,7 @@ static int prepare_one(vr_context *c) {
       f[30] = bits((int32_t)(uint32_t)(addr & 0xFFFFFFFFull));
       f[31] = bits((int32_t)(uint32_t)(addr >> 32));
     }
-    VR_HIP(c, hipMemcpyAsync(c->dWalls.p + 96, f, 32 * 4, hipMemcpyHostToDevice, c->stream));
+    VR_HIP(c, hipMemcpyAsync(c->dWalls.p + (size_t)c->counterSlot * VR_WALL_TABLE, slotHost, VR_WALL_TABLE * 4, hipMemcpyHostToDevice, c->stream));
   }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (redoConfig)
@@ -1654,6 +1807,24 @@ static void size_bins(int D, uint64_t count, uint32_t perBin, TraceParams &p, ui
   }
 }
 
+// The LOOSE bins of a scene with relief (TraceParams, round 4): a grid a third as fine per axis as the tight one p.binT*
+// describes — they hold the grazing rays, about a tenth of all — whose cursors and record slots (+ an overflow region of
+// p.ovCap slots) lie behind the tight bins' in the same two buffers.
+static void size_loose(int D, TraceParams &p) {
+  p.looseT1 = std::max(1, p.binT1 / 3);
+  if (D == 2) {
+    p.looseT2 = 1;
+    p.looseTiles = 1;
+    p.looseNumBins = (uint32_t)p.looseT1;
+  } else {
+    p.looseT2 = std::max(1, p.binT2 / 3);
+    p.looseTiles = (p.looseT1 + 7) / 8;
+    p.looseNumBins = (uint32_t)p.looseTiles * (uint32_t)((p.looseT2 + 7) / 8) * 64u;
+  }
+  p.looseCntBase = (p.numBins + 1u + 3u) & ~3u;
+  p.looseSlotBase = p.numBins * p.binCap + p.ovCap;
+}
+
 // what one trace launch of a batch needs beyond the prepared parameters
 struct LaunchDesc {
   const TraceParams *params;
@@ -1661,6 +1832,9 @@ struct LaunchDesc {
   int traceMode, kernelParticle;
   bool absorb;
   hipFunction_t userKernel; // a run-time model's kernel, or nullptr
+  bool relief = false;      // flat with relief: a second launch (looseMode, looseGrid) traces the loose bins
+  int looseMode = 0;
+  unsigned looseGrid = 0;
 };
 
 static hipEvent_t &event_at(std::vector<hipEvent_t> &v, size_t i, vr_context *c, int &rc) {
@@ -1685,6 +1859,10 @@ static TraceParams batch_params(vr_context *c, const LaunchDesc &L, uint64_t fir
   size_bins(c->geo.D, count, c->raysPerBin, p, nbBatch); // (<= the grid the buffers were sized for)
   nbBatch = std::min(nbBatch, c->numBins);
   p.numBins = nbBatch;
+  if (L.relief)
+    size_loose(c->geo.D, p); // (p.ovCap = the batch capacity: the tight bins' overflow region keeps its full size)
+  else
+    p.reliefCoarse = nullptr;
   {
     // bins per queue grab: ~1024 rays for big batches, but never so many that a small
     // batch (a short last one, a small launch) is handed to a few waves only
@@ -1716,7 +1894,7 @@ static int run_batch(vr_context *c, const std::vector<LaunchDesc> &group, uint64
   int rc = VR_OK;
   const bool keepRng = !group[0].absorb; // records carry the RNG cursors
   const TraceParams pg = batch_params(c, group[0], first, count);
-  VR_HIP(c, hipMemsetAsync(pg.binCount, 0, ((size_t)pg.numBins + 1) * 4, c->stream));
+  VR_HIP(c, hipMemsetAsync(pg.binCount, 0, (pg.reliefCoarse ? (size_t)pg.looseCntBase + pg.looseNumBins + 1 : (size_t)pg.numBins + 1) * 4, c->stream));
   hipEvent_t g0 = event_at(c->evG, 2 * genNo, c, rc), g1 = event_at(c->evG, 2 * genNo + 1, c, rc);
   if (rc != VR_OK)
     return rc;
@@ -1733,7 +1911,8 @@ static int run_batch(vr_context *c, const std::vector<LaunchDesc> &group, uint64
     VR_HIP(c, hipEventRecord(k0, c->stream));
     // a small batch does not need the whole persistent grid: one wave per 64 rays is plenty
     const unsigned gridBatch = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(L.grid, ((uint64_t)count + 255) / 256));
-    if (L.userKernel) {
+    if (L.relief && std::getenv("VR_SKIP_TIGHT")) { // (diagnostics: the loose launch alone — the result is incomplete)
+    } else if (L.userKernel) {
       TraceParams pk = p;
       void *args[] = {&pk};
       VR_HIP(c, hipModuleLaunchKernel(L.userKernel, gridBatch, 1, 1, VR_BLOCK, 1, 1, L.traceMode == 4 ? p.smallBytes : 0, c->stream,
@@ -1743,6 +1922,29 @@ static int run_batch(vr_context *c, const std::vector<LaunchDesc> &group, uint64
     }
     VR_HIP(c, hipEventRecord(k1, c->stream));
     ++traceNo;
+    if (L.relief && !std::getenv("VR_SKIP_LOOSE")) { // (VR_SKIP_LOOSE: diagnostics, the tight launch alone — the result is incomplete)
+      // the loose bins (the grazing rays, filed apart by the generator): the kernel for structured scenes over the second
+      // set of bins — the same buffers from their loose parts on, a single queue
+      TraceParams q = p;
+      q.binCount = p.binCount + p.looseCntBase;
+      q.slotRec = p.slotRec + (size_t)p.looseSlotBase * 8;
+      q.numBins = p.looseNumBins;
+      q.reliefCoarse = nullptr;
+      q.numQueues = 1;
+      {
+        const uint64_t waves = std::min<uint64_t>(L.looseGrid, ((uint64_t)count / 8 + 255) / 256) * (VR_BLOCK / 64);
+        q.chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, q.numBins / std::max<uint64_t>(waves * 2, 1)));
+      }
+      VR_HIP(c, hipMemsetAsync(q.workCounter, 0, VR_QUEUES * VR_QUEUE_STRIDE * 8, c->stream));
+      hipEvent_t l0 = event_at(c->evK, 2 * traceNo, c, rc), l1 = event_at(c->evK, 2 * traceNo + 1, c, rc);
+      if (rc != VR_OK)
+        return rc;
+      VR_HIP(c, hipEventRecord(l0, c->stream));
+      const unsigned gridLoose = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(L.looseGrid, ((uint64_t)count / 4 + 255) / 256));
+      VR_HIP(c, launch_trace(q, c->geo.D, c->geo.geo, L.kernelParticle, L.looseMode, gridLoose, c->stream));
+      VR_HIP(c, hipEventRecord(l1, c->stream));
+      ++traceNo;
+    }
   }
   return VR_OK;
 }
@@ -1763,13 +1965,15 @@ int vr_apply_launch(vr_context *c) {
   // same record format (with / without the RNG cursors)
   std::vector<std::vector<LaunchDesc>> groups;
   if (nPart == 1) {
-    groups.push_back({LaunchDesc{&c->params, c->grid, c->traceMode, c->kernelParticle, c->absorb, c->userKernel}});
+    groups.push_back({LaunchDesc{&c->params, c->grid, c->traceMode, c->kernelParticle, c->absorb, c->userKernel, c->reliefScene,
+                                 c->looseMode, c->looseGrid}});
   } else {
     for (const ParticleLaunch &L : c->launches) {
-      const LaunchDesc d{&L.params, L.grid, L.traceMode, L.kernelParticle, L.absorb, L.userKernel};
+      const LaunchDesc d{&L.params, L.grid, L.traceMode, L.kernelParticle, L.absorb, L.userKernel, L.relief, L.looseMode, L.looseGrid};
       bool placed = false;
       for (auto &g : groups)
-        if (g[0].absorb == d.absorb && g[0].params->ee == d.params->ee && g[0].params->eeGrid == d.params->eeGrid) {
+        if (g[0].absorb == d.absorb && g[0].params->ee == d.params->ee && g[0].params->eeGrid == d.params->eeGrid &&
+            g[0].relief == d.relief) { // (relief: the generator's bins are laid out differently)
           g.push_back(d);
           placed = true;
           break;
@@ -1902,8 +2106,8 @@ int vr_apply_finish(vr_context *c) {
     float m = 0.f;
     VR_HIP(c, hipEventElapsedTime(&m, c->evK[2 * b], c->evK[2 * b + 1]));
     kms += m;
-    if (nPart > 1) // (batches of a group follow each other: launch b belongs to particle ... of its group; the
-      ;            //  per-particle kernel time is not broken out)
+    if (std::getenv("VR_PRINT_LAUNCHES")) // (diagnostics: a scene with relief runs two trace launches per batch)
+      std::fprintf(stderr, "[vr] trace launch %zu: %.3f ms\n", b, m);
   }
   i.timeTraceKernel = kms * 1e-3;
   double gms = 0.0;
@@ -1972,6 +2176,9 @@ int vr_apply_prepare(vr_context *c) {
     L.numData = c->numData;
     L.dataBase = base;
     L.userKernel = c->userKernel;
+    L.relief = c->reliefScene;
+    L.looseMode = c->looseMode;
+    L.looseGrid = c->looseGrid;
     if (c->havePrimSticking) { // this particle's sticking map: the next prepare would overwrite the shared buffer
       L.primSticking = c->dPrimSticking.p;
       L.params.primSticking = L.primSticking;

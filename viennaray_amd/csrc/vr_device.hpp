@@ -362,13 +362,16 @@ __device__ __forceinline__ void hit_clear(HitRec &h) {
 // at every use.  The compact ray records' decode (vr_trace.hip) reads its four scalars from here in every kernel; the
 // absorbing flat-scene kernel (8 waves per SIMD, 78 spilled SGPRs) also its wall and scene-box frame: the *_lds
 // variants below (C2 trace 6.5 -> 6.3 ms; the general kernels measured 3 % SLOWER with them and keep the arguments).
-constexpr int VR_WALL_TABLE = 128; // floats
+constexpr int VR_WALL_TABLE = 144; // floats
 enum { VR_F_SRC_PLANE = 96, VR_F_RAYDIR = 97, VR_F_FIRSTDIR = 98, VR_F_SECONDDIR = 99, VR_F_EXTRA_LO = 100, VR_F_EXTRA_HI = 101,
        VR_F_LO1 = 102 /* lo1, hi1, lo2, hi2 */, VR_F_WALL_LO_R = 106, VR_F_WALL_HI_R = 107, VR_F_SCENE_LO = 108, VR_F_SCENE_HI = 111,
        VR_F_PQ_PAD = 114, VR_F_BC0 = 115, VR_F_BC1 = 116, VR_F_NB_DIST = 117,
        // the height field over the source plane (HeightFieldParams; NX = 0: none)
        VR_F_HF_LO1 = 118, VR_F_HF_LO2 = 119, VR_F_HF_INVT = 120, VR_F_HF_TILE = 121, VR_F_HF_TOP = 122, VR_F_HF_SIGN = 123,
-       VR_F_HF_NX = 124, VR_F_HF_NY = 125, VR_F_HF_PTR_LO = 126, VR_F_HF_PTR_HI = 127 };
+       VR_F_HF_NX = 124, VR_F_HF_NY = 125, VR_F_HF_PTR_LO = 126, VR_F_HF_PTR_HI = 127,
+       // the relief field's fine tiles (ReliefParams; NX = 0: none): relief_clip below
+       VR_F_RF_LO1 = 128, VR_F_RF_LO2 = 129, VR_F_RF_INVT = 130, VR_F_RF_TILE = 131, VR_F_RF_NX = 132, VR_F_RF_NY = 133,
+       VR_F_RF_PTR_LO = 134, VR_F_RF_PTR_HI = 135 };
 
 __device__ __forceinline__ void hit_walls(const TraceParams &p, const float *__restrict__ wallS, const V3 &o,
                                           const V3 &d, float tnear, HitRec &h) {
@@ -464,6 +467,77 @@ __device__ __forceinline__ void hit_walls_lds(const TraceParams &p, const float 
   }
   if (hw.geom == 0 && hw.t <= h.t)
     h = hw;
+}
+
+// ---------------------------------------------------------------------------
+// A ray's stretch through the LOCAL relief (ReliefParams, vr_types.hpp) instead of through the scene box.  The tiles of
+// the relief field under the ray are walked from t0 to t1 (its stretch inside the scene box); inside a tile the ray can
+// only meet a primitive while its height lies within the tile's [lo, hi] — every primitive that reaches into the tile
+// lies in that range — so [tA, tB], the hull of those sub-stretches over all tiles walked, holds every point at which
+// the ray meets ANY primitive (closest hit and neighbour crossings alike).  tA > tB: the ray meets nothing.
+// Rounding: the walk may file a sliver of the ray under the neighbouring tile; the field's pad (1e-5 of the largest
+// coordinate, three orders above the rounding of a position) makes that tile's range hold the primitive as well.
+// After VR_RELIEF_STEPS tiles (a grazing ray that the generator did not file apart) the rest of the stretch is kept whole.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, bool on, const V3 &o, const V3 &d, float t0, float t1,
+                                            float &tA, float &tB) {
+  typedef float F2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) F2 *GlobalF2;
+  const GlobalF2 field = reinterpret_cast<GlobalF2>(((unsigned long long)__float_as_uint(wallS[VR_F_RF_PTR_HI]) << 32) |
+                                                    __float_as_uint(wallS[VR_F_RF_PTR_LO]));
+  const int ax = __float_as_int(wallS[VR_F_RAYDIR]), a1 = __float_as_int(wallS[VR_F_FIRSTDIR]), a2 = __float_as_int(wallS[VR_F_SECONDDIR]);
+  const int nx = __float_as_int(wallS[VR_F_RF_NX]), ny = __float_as_int(wallS[VR_F_RF_NY]);
+  const float T = wallS[VR_F_RF_TILE], invT = wallS[VR_F_RF_INVT], lo1 = wallS[VR_F_RF_LO1], lo2 = wallS[VR_F_RF_LO2];
+  const float oz = getc(o, ax), dz = getc(d, ax), o1 = getc(o, a1), d1 = getc(d, a1);
+  const float o2 = ny > 1 ? getc(o, a2) : 0.f, d2 = ny > 1 ? getc(d, a2) : 0.f;
+  const float big = 3.0e38f;
+  tA = big;
+  tB = -big;
+  int ix = (int)floorf((o1 + d1 * t0 - lo1) * invT), iy = ny > 1 ? (int)floorf((o2 + d2 * t0 - lo2) * invT) : 0;
+  ix = ix < 0 ? 0 : (ix >= nx ? nx - 1 : ix);
+  iy = iy < 0 ? 0 : (iy >= ny ? ny - 1 : iy);
+  const int sx = d1 > 0.f ? 1 : -1, sy = d2 > 0.f ? 1 : -1;
+  const float inv1 = d1 != 0.f ? 1.0f / d1 : 0.f, inv2 = d2 != 0.f ? 1.0f / d2 : 0.f;
+  float tx = d1 != 0.f ? (lo1 + (float)(ix + (d1 > 0.f ? 1 : 0)) * T - o1) * inv1 : big;
+  float ty = d2 != 0.f ? (lo2 + (float)(iy + (d2 > 0.f ? 1 : 0)) * T - o2) * inv2 : big;
+  const float dtx = T * fabsf(inv1), dty = T * fabsf(inv2);
+  const float invz = dz != 0.f ? 1.0f / dz : 0.f;
+  float tc = t0;
+  bool go = on && t0 <= t1;
+  for (int s = 0; ballot64(go); ++s) {
+    if (go) {
+      const float tn = fminf(fminf(tx, ty), t1);
+      const F2 f = field[iy * nx + ix];
+      const float z0 = oz + dz * tc, z1 = oz + dz * tn;
+      if (fmaxf(z0, z1) >= f.x && fminf(z0, z1) <= f.y) {
+        float ta = tc, tb = tn;
+        if (dz != 0.f) {
+          const float q0 = (f.x - oz) * invz, q1 = (f.y - oz) * invz;
+          ta = fmaxf(ta, fminf(q0, q1));
+          tb = fminf(tb, fmaxf(q0, q1));
+        }
+        tA = fminf(tA, ta);
+        tB = fmaxf(tB, tb);
+      }
+      if (!(tn < t1)) {
+        go = false;
+      } else if (s == VR_RELIEF_STEPS - 1) { // (too many tiles: the rest of the stretch as it is)
+        tA = fminf(tA, tn);
+        tB = t1;
+        go = false;
+      } else {
+        if (tx <= ty) {
+          ix += sx;
+          tx += dtx;
+        } else {
+          iy += sy;
+          ty += dty;
+        }
+        go = (unsigned)ix < (unsigned)nx && (unsigned)iy < (unsigned)ny; // (beyond the field: beyond the scene box)
+        tc = tn;
+      }
+    }
+  }
 }
 
 __device__ __forceinline__ V3 safe_inverse(const V3 &d) {
@@ -953,7 +1027,8 @@ constexpr unsigned VR_PQ_RECORDS = 2 * 52;
 
 // lst: 128 dwords of LDS private to this wave
 // FRAME_LDS: the scene box and the padding come from the LDS frame `wallS` (see hit_walls_lds)
-template <int GEO, bool CREDIT, bool FRAME_LDS = false, bool KEEPQ = false>
+// RELIEF: the rays are clipped to the local relief (relief_clip) instead of to the scene box
+template <int GEO, bool CREDIT, bool FRAME_LDS = false, bool KEEPQ = false, bool RELIEF = false>
 __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
                                               HitRec &h, volatile VR_LDS unsigned *lst, PqCands &cd,
                                               const float *__restrict__ wallS VR_DIAG_ARGS) {
@@ -965,7 +1040,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   const float tz0 = ((FRAME_LDS ? wallS[VR_F_SCENE_LO + 2] : p.sceneLo[2]) - o.z) * inv.z, tz1 = ((FRAME_LDS ? wallS[VR_F_SCENE_HI + 2] : p.sceneHi[2]) - o.z) * inv.z;
   const float tIn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
   const float tOut = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-  const bool valid = part && tIn <= tOut;
+  bool valid = part && tIn <= tOut;
   cd.count = 0;
   cd.local = 0ull;
   const float big = 3.0e38f;
@@ -974,9 +1049,19 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
     return true; // nobody reaches the scene box: every ray misses the geometry
   // (Q starts at the ray's origin where that lies inside the box, not at tnear: the neighbour test
   //  accepts any t > 0)
-  const float tQ = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+  float tQ = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.f));
+  float tEnd = tOut;
+  if (RELIEF && !(p.debugFlags & 512u)) { // (flag 512: the scene box's clip, for comparison)
+    float tA, tB;
+    relief_clip(wallS, valid, o, d, tQ, tOut, tA, tB);
+    valid = valid && tA <= tB;
+    if (!ballot64(valid))
+      return true; // no ray's height meets the relief under it
+    tQ = tA;
+    tEnd = tB;
+  }
   const float ax = o.x + d.x * tQ, ay = o.y + d.y * tQ, az = o.z + d.z * tQ;
-  const float bx = o.x + d.x * tOut, by = o.y + d.y * tOut, bz = o.z + d.z * tOut;
+  const float bx = o.x + d.x * tEnd, by = o.y + d.y * tEnd, bz = o.z + d.z * tEnd;
   float qlx = valid ? fminf(ax, bx) : big, qly = valid ? fminf(ay, by) : big, qlz = valid ? fminf(az, bz) : big;
   float qhx = valid ? fmaxf(ax, bx) : -big, qhy = valid ? fmaxf(ay, by) : -big, qhz = valid ? fmaxf(az, bz) : -big;
   wave_minmax6(qlx, qly, qlz, qhx, qhy, qhz);

@@ -40,6 +40,7 @@ hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, un
 size_t wide_tree_entries(unsigned n);
 hipError_t launch_wide_tree(const SetupParams &s, unsigned *out3, hipStream_t st);
 hipError_t launch_height_field(const HeightFieldParams &q, hipStream_t st);
+hipError_t launch_relief_field(const ReliefParams &q, hipStream_t st);
 hipError_t launch_disk4(const float *points3, unsigned n, float radius, int D, float *disk4, hipStream_t st);
 // post-processing on the device (vr_setup.hip)
 hipError_t launch_disk_areas(const float *disk4, const float *normal3, unsigned n, const AreaParams &p, float *out,

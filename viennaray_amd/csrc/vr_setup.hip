@@ -1020,6 +1020,98 @@ hipError_t launch_height_field(const HeightFieldParams &q, hipStream_t st) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// relief field over the source plane (ReliefParams, vr_types.hpp): fine tiles {lo, hi} for the tracer's per-ray clip
+// (relief_clip), coarse tiles {mid height, largest fine thickness} for the generator's sort key
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void relief_prim_box(const ReliefParams &q, unsigned i, float (&lo)[3], float (&hi)[3]) {
+  const float4 *pr = reinterpret_cast<const float4 *>(q.prims);
+  if (q.geo == 0) {
+    const float4 c = pr[2 * (size_t)i], n = pr[2 * (size_t)i + 1];
+    const float cc[3] = {c.x, c.y, c.z}, nn[3] = {n.x, n.y, n.z};
+    for (int k = 0; k < 3; ++k) { // the disc's own extent along axis k (as the BVH's boxes)
+      const float e = c.w * sqrtf(fmaxf(0.f, 1.f - nn[k] * nn[k])) * 1.0001f;
+      lo[k] = cc[k] - e;
+      hi[k] = cc[k] + e;
+    }
+  } else {
+    const float4 a = pr[4 * (size_t)i], e1 = pr[4 * (size_t)i + 1], e2 = pr[4 * (size_t)i + 2];
+    const float v0[3] = {a.x, a.y, a.z}, v1[3] = {a.x - e1.x, a.y - e1.y, a.z - e1.z}, v2[3] = {a.x + e2.x, a.y + e2.y, a.z + e2.z};
+    for (int k = 0; k < 3; ++k) {
+      lo[k] = fminf(v0[k], fminf(v1[k], v2[k]));
+      hi[k] = fmaxf(v0[k], fmaxf(v1[k], v2[k]));
+    }
+  }
+}
+
+__global__ void relief_field_kernel(ReliefParams q) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= q.n)
+    return;
+  float lo[3], hi[3];
+  relief_prim_box(q, i, lo, hi);
+  // (the pad — 1e-5 of the largest coordinate — is far above the rounding of a ray's position and of the tile walk: a
+  //  point of a primitive that the walk files under the neighbouring tile is still inside that tile's range)
+  const unsigned zl = f2ord(lo[q.ax] - q.pad), zh = f2ord(hi[q.ax] + q.pad);
+  const int ix0 = min(max((int)floorf((lo[q.a1] - q.pad - q.lo1) * q.invTile), 0), q.nx - 1);
+  const int ix1 = min(max((int)floorf((hi[q.a1] + q.pad - q.lo1) * q.invTile), 0), q.nx - 1);
+  int iy0 = 0, iy1 = 0;
+  if (q.ny > 1) {
+    iy0 = min(max((int)floorf((lo[q.a2] - q.pad - q.lo2) * q.invTile), 0), q.ny - 1);
+    iy1 = min(max((int)floorf((hi[q.a2] + q.pad - q.lo2) * q.invTile), 0), q.ny - 1);
+  }
+  for (int iy = iy0; iy <= iy1; ++iy)
+    for (int ix = ix0; ix <= ix1; ++ix) {
+      atomicMin(&q.rawLo[iy * q.nx + ix], zl);
+      atomicMax(&q.rawHi[iy * q.nx + ix], zh);
+    }
+}
+
+// one thread per COARSE tile: its k x k fine tiles -> {lo, hi} floats, the coarse entry and the statistics
+__global__ void relief_finish_kernel(ReliefParams q) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= q.cnx * q.cny)
+    return;
+  const int cx = t % q.cnx, cy = t / q.cnx;
+  float mlo = 3.0e38f, mhi = -3.0e38f, thick = 0.f;
+  unsigned filled = 0;
+  for (int dy = 0; dy < q.k; ++dy)
+    for (int dx = 0; dx < q.k; ++dx) {
+      const int ix = cx * q.k + dx, iy = cy * q.k + dy;
+      if (ix >= q.nx || iy >= q.ny)
+        continue;
+      const unsigned ul = q.rawLo[iy * q.nx + ix], uh = q.rawHi[iy * q.nx + ix];
+      float2 f = make_float2(3.0e38f, -3.0e38f); // (a tile nothing reaches into: no height overlaps it)
+      if (uh != 0u) {
+        f = make_float2(ord2f(ul), ord2f(uh));
+        mlo = fminf(mlo, f.x);
+        mhi = fmaxf(mhi, f.y);
+        thick = fmaxf(thick, f.y - f.x);
+        ++filled;
+      }
+      reinterpret_cast<float2 *>(q.fine)[iy * q.nx + ix] = f;
+    }
+  reinterpret_cast<float2 *>(q.coarse)[t] = filled ? make_float2(0.5f * (mlo + mhi), thick) : make_float2(q.emptyMid, 0.f);
+  if (filled) {
+    atomicAdd(&q.stats[0], 1u);
+    atomicAdd(&q.stats[1], (unsigned)(4096.f * thick * thick / (thick * thick + q.travel * q.travel)));
+  }
+}
+
+hipError_t launch_relief_field(const ReliefParams &q, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(q.rawLo, 0xFF, (size_t)q.nx * q.ny * 4, st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(q.rawHi, 0, (size_t)q.nx * q.ny * 4, st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(q.stats, 0, 2 * 4, st);
+  if (e != hipSuccess)
+    return e;
+  if (q.n)
+    hipLaunchKernelGGL(relief_field_kernel, dim3((q.n + 255) / 256), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(relief_finish_kernel, dim3((q.cnx * q.cny + 255) / 256), dim3(256), 0, st, q);
+  return hipGetLastError();
+}
+
 // builds the tree from s.sbox (sorted, padded boxes); out3 = the root's {first child entry,
 // child count | VR_WIDE_PRIMS if the root's children are the primitives themselves, 0}
 hipError_t launch_wide_tree(const SetupParams &s, unsigned *out3, hipStream_t st) {

@@ -127,6 +127,56 @@ template <int D> __device__ __forceinline__ unsigned bin_of(const TraceParams &p
   return tile * 64u + (col << 3 | ((col & 1u) ? 7u - row : row));
 }
 
+// Sort key on a scene that is flat WITH RELIEF (TraceParams, round 4): the cell of the ray's PREDICTED first hit — the
+// crossing of the plane through the mid height of the coarse relief tile under the previous guess, two look-ups starting
+// from the sort plane — so that the rays of a wave meet the surface, not some plane above or below it, in one
+// neighbourhood whatever their angles.  A ray whose stretch through the local slab is long (thickness x tan(theta) >
+// reliefTravel: a grazing ray) is filed in the coarser LOOSE bins instead (bit 31 of the result): one such ray in a wave
+// stretches the packet query's box over dozens of cells.  Like bin_of this only orders the work.
+template <int D> __device__ __forceinline__ unsigned bin_of_relief(const TraceParams &p, const V3 &org, const V3 &dir) {
+  typedef float F2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) F2 *GlobalF2;
+  const GlobalF2 coarse = (GlobalF2)p.reliefCoarse;
+  const float dr = getc(dir, p.rayDir);
+  const float drs = fabsf(dr) > 1e-6f ? dr : copysignf(1e-6f, dr == 0.f ? -p.posNeg : dr);
+  // (the key only orders the work: the approximate reciprocal and fused multiply-adds will do, and the look-ups take
+  //  the unfolded position, clamped — a ray that crosses a side wall first is sorted a little less well)
+  const float inv = __builtin_amdgcn_rcpf(drs);
+  const float o1 = getc(org, p.firstDir), d1 = getc(dir, p.firstDir);
+  const float o2 = D == 3 ? getc(org, p.secondDir) : 0.f, d2 = D == 3 ? getc(dir, p.secondDir) : 0.f;
+  const float a1 = (o1 - p.rcLo1) * p.rcInvT, b1 = d1 * p.rcInvT, a2 = (o2 - p.rcLo2) * p.rcInvT, b2 = d2 * p.rcInvT;
+  float t = fmaxf((p.keyCoord - p.srcCoord) * inv, 0.f), thick = 0.f;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (it == p.reliefLookups)
+      break;
+    int cx = (int)__builtin_fmaf(b1, t, a1);
+    cx = cx < 0 ? 0 : (cx >= p.rcNx ? p.rcNx - 1 : cx);
+    int cy = 0;
+    if (D == 3) {
+      cy = (int)__builtin_fmaf(b2, t, a2);
+      cy = cy < 0 ? 0 : (cy >= p.rcNy ? p.rcNy - 1 : cy);
+    }
+    const F2 f = coarse[cy * p.rcNx + cx];
+    t = fmaxf((f.x - p.srcCoord) * inv, 0.f);
+    thick = f.y;
+  }
+  const float u1 = fold_unit((__builtin_fmaf(d1, t, o1) - p.lo1) * p.invExt1, p.bc0);
+  const float sin2 = fmaxf(0.f, 1.f - dr * dr);
+  const bool loose = thick * thick * sin2 > p.reliefTravel * p.reliefTravel * (drs * drs);
+  const int T1 = loose ? p.looseT1 : p.binT1, T2 = loose ? p.looseT2 : p.binT2, tiles = loose ? p.looseTiles : p.binTiles;
+  int c1 = (int)(u1 * (float)T1);
+  c1 = c1 < 0 ? 0 : (c1 >= T1 ? T1 - 1 : c1);
+  if (D == 2)
+    return (unsigned)c1 | (loose ? 0x80000000u : 0u);
+  const float u2 = fold_unit((__builtin_fmaf(d2, t, o2) - p.lo2) * p.invExt2, p.bc1);
+  int c2 = (int)(u2 * (float)T2);
+  c2 = c2 < 0 ? 0 : (c2 >= T2 ? T2 - 1 : c2);
+  const unsigned tile = (unsigned)(c2 >> 3) * (unsigned)tiles + (unsigned)(c1 >> 3);
+  const unsigned row = (unsigned)c2 & 7u, col = (unsigned)c1 & 7u;
+  return (tile * 64u + (col << 3 | ((col & 1u) ? 7u - row : row))) | (loose ? 0x80000000u : 0u);
+}
+
 // ---------------------------------------------------------------------------
 // gen_kernel: ray index -> ray record
 // ---------------------------------------------------------------------------
@@ -165,13 +215,14 @@ __device__ __forceinline__ unsigned gen_store(const TraceParams &p, unsigned i, 
 // The bin cursor's returning atomic is the one long latency of a ray; it is issued as soon as the ray's bin is
 // known and its answer is used one loop pass later, after the NEXT ray's seeding chain: the wave computes while
 // its own atomic is under way instead of leaving that to the other waves of the SIMD.
-template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
+// RELIEF: the sort key of bin_of_relief and its second, loose set of bins
+template <int D, bool KEEP, bool RELIEF> __global__ __launch_bounds__(VR_BLOCK) void gen_kernel(const TraceParams p) {
   constexpr int NS = D == 3 ? 4 : 3;
   const bool binned = p.binCount && !(p.debugFlags & 64u); // flag 64: timing experiment, no binning
   bool havePrev = false;
   V3 po = mk(0, 0, 0), pd = mk(0, 0, 1);
   unsigned pi = 0, pbin = 0, ppos = 0;
-  u64 plo = 0, phi = 0;
+  u64 phi = 0;
   for (unsigned i = blockIdx.x * VR_BLOCK + threadIdx.x;; i += gridDim.x * VR_BLOCK) {
     const bool cur = i < p.batchCount;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1);
@@ -184,12 +235,18 @@ template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_kern
       int k = 0;
       source_sample<D>(p, [&]() { return out[k++]; }, o, d); // k is a compile-time sequence after unrolling
       if (binned)
-        b = bin_of<D>(p, o, project_dir<D>(d));
+        b = RELIEF ? bin_of_relief<D>(p, o, project_dir<D>(d)) : bin_of<D>(p, o, project_dir<D>(d));
     }
     if (havePrev) { // the previous ray of this lane: its slot has arrived
       unsigned slot = pi;
       if (binned) {
-        if (ppos < p.binCap)
+        if (RELIEF && (pbin >> 31)) { // a loose bin: its slots and its overflow region lie behind the tight bins'
+          const unsigned lb = pbin & 0x7FFFFFFFu;
+          if (ppos < p.binCap)
+            slot = p.looseSlotBase + lb * p.binCap + ppos;
+          else
+            slot = p.looseSlotBase + p.looseNumBins * p.binCap + atomicAdd(&p.binCount[p.looseCntBase + p.looseNumBins], 1u);
+        } else if (ppos < p.binCap)
           slot = pbin * p.binCap + ppos;
         else
           slot = p.numBins * p.binCap + atomicAdd(&p.binCount[p.numBins], 1u); // < ovCap by construction
@@ -211,12 +268,11 @@ template <int D, bool KEEP> __global__ __launch_bounds__(VR_BLOCK) void gen_kern
     if (!cur)
       break;
     if (binned)
-      ppos = atomicAdd(&p.binCount[b], 1u); // (answer used in the next pass)
+      ppos = atomicAdd(&p.binCount[(RELIEF && (b >> 31)) ? p.looseCntBase + (b & 0x7FFFFFFFu) : b], 1u); // (answer used in the next pass)
     po = o;
     pd = d;
     pi = i;
     pbin = b;
-    plo = lo;
     phi = hi;
     havePrev = true;
   }
@@ -456,14 +512,24 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 #ifndef VR_FLAT_WAVES
 #define VR_FLAT_WAVES 6    // ... of the general flat-scene kernel (MODE 3)
 #endif
+// MODE 5 / 6: MODE 1 / 3 for a scene that is flat WITH RELIEF: the packet query clips its rays to the local relief
+// (relief_clip, vr_device.hpp) instead of to the scene box; the generator has filed the grazing rays apart (TraceParams,
+// round 4), and those are traced by a MODE 2 / 0 launch of their own.
+#ifndef VR_RELIEF_WAVES
+#define VR_RELIEF_WAVES 8  // waves per SIMD of the absorbing relief kernel (MODE 5)
+#endif
+constexpr int vr_mode_waves(int m) {
+  return m == 5 ? VR_RELIEF_WAVES : m == 1 ? 8 : (m == 2 ? 7 : ((m == 3 || m == 6) ? VR_FLAT_WAVES : (m == 4 ? VR_SMALL_WAVES : VR_GENERAL_WAVES)));
+}
 template <int D, int GEO, int PARTICLE, int MODE_>
 __global__ __launch_bounds__(VR_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
-__attribute__((amdgpu_waves_per_eu(MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? VR_SMALL_WAVES : VR_GENERAL_WAVES))), MODE_ == 1 ? 8 : (MODE_ == 2 ? 7 : (MODE_ == 3 ? VR_FLAT_WAVES : (MODE_ == 4 ? VR_SMALL_WAVES : VR_GENERAL_WAVES)))))) void
+__attribute__((amdgpu_waves_per_eu(vr_mode_waves(MODE_), vr_mode_waves(MODE_)))) void
 trace_kernel(const TraceParams p) {
   constexpr bool SMALL = MODE_ == 4;
-  constexpr bool FRAME_LDS = MODE_ == 1; // (the wall / scene-box frame from LDS: hit_walls_lds, vr_device.hpp)
-  constexpr bool FOLLOW = MODE_ == 3;    // (follow-up segments inside the round of a packet query: end of the round)
-  constexpr int MODE = SMALL ? 0 : MODE_;
+  constexpr bool RELIEF = MODE_ == 5 || MODE_ == 6;
+  constexpr int MODE = SMALL ? 0 : (MODE_ == 5 ? 1 : (MODE_ == 6 ? 3 : MODE_));
+  constexpr bool FRAME_LDS = MODE == 1; // (the wall / scene-box frame from LDS: hit_walls_lds, vr_device.hpp)
+  constexpr bool FOLLOW = MODE == 3;    // (follow-up segments inside the round of a packet query: end of the round)
   constexpr bool ABSORB = MODE == 1 || MODE == 2;
   // PARTICLE 0 / 1: DiffuseParticle / SpecularParticle compiled in.  PARTICLE 2 (P_EXT): the
   // extended kernel — particle kind, data labels, WDIST crediting and mean-free-path scattering
@@ -794,7 +860,7 @@ trace_kernel(const TraceParams p) {
         if (active) {
           DIAG(12);
         }
-        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + waveInBlock * 128u), cands, wallS VR_DIAG_PASS);
+        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW, RELIEF>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + waveInBlock * 128u), cands, wallS VR_DIAG_PASS);
         pqCredit = PQ_CREDIT && packetDone;
         pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
         pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;
@@ -1220,14 +1286,31 @@ trace_kernel(const TraceParams p) {
           const float tQ = fmaxf(tEnter, fmaxf(fminf(tz0, tz1), 0.f));
           const float tOut = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
           reaches = tIn <= tOut; // (as pq_hit_packet's `valid`: otherwise no part of the segment is inside the scene box)
-          const float ax = org.x + dir.x * tQ, ay = org.y + dir.y * tQ, az = org.z + dir.z * tQ;
-          const float bx = org.x + dir.x * tOut, by = org.y + dir.y * tOut, bz = org.z + dir.z * tOut;
+          float tBeg = tQ, tEnd = tOut;
+          if (RELIEF && !(p.debugFlags & 512u)) {
+            // (as the query's own rays: the stretch through the local relief; none — the ray has risen clear of it —
+            //  and the segment cannot meet the geometry)
+            float tA, tB;
+            relief_clip(wallS, reaches, org, dir, tQ, tOut, tA, tB);
+            reaches = reaches && tA <= tB;
+            tBeg = tA;
+            tEnd = tB;
+          }
+          const float ax = org.x + dir.x * tBeg, ay = org.y + dir.y * tBeg, az = org.z + dir.z * tBeg;
+          const float bx = org.x + dir.x * tEnd, by = org.y + dir.y * tEnd, bz = org.z + dir.z * tEnd;
           // (inside Q proper: the padding absorbs the rounding of the clip, as it does for the query's own rays)
           const float pad = p.pqPad;
           const float lx = __uint_as_float(ql.x) + pad, ly = __uint_as_float(ql.y) + pad, lz = __uint_as_float(ql.z) + pad;
           const float hx = __uint_as_float(qh.x) - pad, hy = __uint_as_float(qh.y) - pad, hz = __uint_as_float(qh.z) - pad;
           inside = !reaches || (fminf(ax, bx) >= lx && fmaxf(ax, bx) <= hx && fminf(ay, by) >= ly && fmaxf(ay, by) <= hy &&
                                 fminf(az, bz) >= lz && fmaxf(az, bz) <= hz);
+          if (RELIEF && (p.debugFlags & 2048u) && !inside) { // EXPERIMENT (wrong results): long continuing rays vanish
+            const float ex = bx - ax, ey = by - ay, ez = bz - az;
+            if ((ex * ex + ey * ey) + ez * ez > p.reliefTravel * p.reliefTravel)
+              active = false;
+          }
+          if (RELIEF && (p.debugFlags & 4096u) && !inside) // EXPERIMENT (wrong results): every continuing ray not finished here vanishes
+            active = false;
         }
         if (ballot64(inside)) {
           bool meets = false;
@@ -1379,8 +1462,19 @@ hipError_t launch_gen(const TraceParams &p, int D, bool keepRng, unsigned maxBlo
   // source: SourceRandom (0: axis-aligned, 1: tilted primary direction), SourceGrid (2), host rays (3)
   const int src = p.hostOrg ? 3 : (p.gridPoints ? 2 : (p.useBasis ? 1 : 0));
   const int key = src * 4 + (D == 2 ? 0 : 2) + (keepRng ? 1 : 0);
+  if (src == 0 && p.reliefCoarse && p.binCount) { // the plain generator on a scene with relief: predicted-hit key, loose bins
+    if (D == 2 && !keepRng)
+      hipLaunchKernelGGL((gen_kernel<2, false, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+    else if (D == 2)
+      hipLaunchKernelGGL((gen_kernel<2, true, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+    else if (!keepRng)
+      hipLaunchKernelGGL((gen_kernel<3, false, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+    else
+      hipLaunchKernelGGL((gen_kernel<3, true, true>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+    return hipGetLastError();
+  }
 #define VR_GEN(K, DD, KEEP)                                                                                           \
-  case K: hipLaunchKernelGGL((gen_kernel<DD, KEEP>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;                     \
+  case K: hipLaunchKernelGGL((gen_kernel<DD, KEEP, false>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;               \
   case 4 + K: hipLaunchKernelGGL((gen_basis_kernel<DD, KEEP>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;            \
   case 8 + K: hipLaunchKernelGGL((gen_grid_kernel<DD, KEEP>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;             \
   case 12 + K: hipLaunchKernelGGL((gen_host_kernel<DD, KEEP>), dim3(grid), dim3(VR_BLOCK), 0, s, p); break;
@@ -1418,6 +1512,10 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
     hipLaunchKernelGGL((trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 3>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 4)
     hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 4>), dim3(grid), dim3(VR_BLOCK), p.smallBytes, s, p);
+  else if (mode == 5)
+    hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 5>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  else if (mode == 6 && GEO == 0 && PARTICLE <= P_EXT)
+    hipLaunchKernelGGL((trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 6>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else
     hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   return hipGetLastError();
@@ -1442,7 +1540,7 @@ template <class F> static auto dispatch_variant(int D, int geo, int particle, F 
 
 hipError_t launch_trace(const TraceParams &p, int D, int geo, int particle, int mode, unsigned grid,
                         hipStream_t s) {
-  if (mode == 1 || mode == 2)
+  if (mode == 1 || mode == 2 || mode == 5)
     particle = 0; // the reflection model is unobservable: one instantiation serves all
   return dispatch_variant(D, geo, particle, [&](auto d, auto g, auto pt) {
     return launch_trace_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(p, mode, grid, s);
@@ -1460,13 +1558,17 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode, unsigned smal
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 3>, VR_BLOCK, 0);
   else if (mode == 4)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 4>, VR_BLOCK, smallBytes);
+  else if (mode == 5)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 5>, VR_BLOCK, 0);
+  else if (mode == 6 && GEO == 0 && PARTICLE <= P_EXT)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 6>, VR_BLOCK, 0);
   else
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 0>, VR_BLOCK, 0);
   return e == hipSuccess ? nb : 2;
 }
 
 int trace_blocks_per_cu(int D, int geo, int particle, int mode, unsigned smallBytes) {
-  if (mode == 1 || mode == 2)
+  if (mode == 1 || mode == 2 || mode == 5)
     particle = 0;
   return dispatch_variant(D, geo, particle, [&](auto d, auto g, auto pt) {
     return occ_t<decltype(d)::value, decltype(g)::value, decltype(pt)::value>(mode, smallBytes);

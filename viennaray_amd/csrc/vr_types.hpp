@@ -54,6 +54,7 @@ constexpr unsigned VR_STACK_GLOBAL = 48;
 constexpr int VR_STACK_LDS = VR_STACK_LDS_ENTRIES;
 // scenes of a few hundred primitives (2-D simulations) live in LDS as a whole — pair nodes, primitive records,
 // neighbourhood, flux accumulators: trace_kernel MODE 4 stages up to this many bytes per block (dynamic LDS)
+constexpr int VR_RELIEF_STEPS = 16; // tiles relief_clip walks under one ray before it falls back to the scene box's exit
 constexpr unsigned VR_SMALL_LDS = 25600; // (up to 17.5 KB: five blocks per CU; up to this: four, still ahead of the HBM path)
 constexpr int VR_SMALL_STACK = 6; // LDS stack entries of that kernel (its trees are shallow)
 
@@ -147,6 +148,41 @@ struct TraceParams {
   const float *globalVec;          // [numGlobalVec][globalStride] or nullptr
   const float *globalScalars;      // [numGlobalScalars] or nullptr
   uint32_t numGlobalVec, globalStride, numGlobalScalars;
+  // ---- round 4 (appended): scenes that are flat WITH RELIEF (ReliefParams below).  The generator sorts a ray by the
+  //      cell of its PREDICTED first hit (two look-ups in the coarse field) and files the rays whose stretch through
+  //      the local slab is long — grazing rays — in a second, coarser set of bins ("loose"), traced by the kernels
+  //      for structured scenes; the flat-scene kernels then see waves whose packet query stays small.
+  const float *reliefCoarse;       // [rcNy][rcNx] x {mid height, largest fine-tile thickness} or nullptr (plain binning)
+  float rcLo1, rcLo2, rcInvT;      // coarse tile (ix, iy) of a point: (coord - rcLo) * rcInvT
+  int32_t rcNx, rcNy;
+  float reliefTravel;              // a ray is loose when thickness x tan(theta) exceeds this
+  uint32_t looseCntBase;           // binCount[looseCntBase + b]: cursor of loose bin b; [looseCntBase + looseNumBins]: their overflow
+  uint32_t looseSlotBase;          // first record slot of the loose bins (their overflow region follows them)
+  uint32_t looseNumBins;
+  int32_t looseT1, looseT2, looseTiles;
+  int32_t reliefLookups;           // coarse look-ups of the generator's hit prediction (1 or 2)
+};
+
+// Relief field over the source plane (vr_setup.hip: relief_field_kernel): per fine tile the [lo, hi] range — along the
+// source axis, padded — of every primitive whose (padded) box meets the tile.  A ray can only meet geometry inside a
+// tile while its own height is within that range: relief_clip (vr_device.hpp) walks the tiles under a ray and returns
+// the stretch that covers all such tiles, which replaces the clip to the SCENE box in the packet query of the
+// flat-scene kernels (trace_kernel MODE 5 / 6).  The coarse field (<= 256 x 256, L2 resident for the generator's random
+// look-ups) holds per coarse tile the mid height of its geometry and the largest thickness of its fine tiles.
+struct ReliefParams {
+  const float *prims;
+  uint32_t n;
+  int32_t geo, ax, a1, a2;
+  float lo1, lo2, invTile, tile, pad;
+  int32_t nx, ny;           // fine tiles
+  int32_t k, cnx, cny;      // a coarse tile = k x k fine tiles
+  float travel;             // statistics: TraceParams::reliefTravel (a ray is loose when thickness x tan(theta) exceeds it)
+  float emptyMid;           // mid height of a coarse tile nothing reaches into
+  uint32_t *rawLo, *rawHi;  // nx * ny ordered-uint minima / maxima
+  float *fine;              // nx * ny x {lo, hi}
+  float *coarse;            // cnx * cny x {mid, max fine thickness}
+  uint32_t *stats;          // [0] non-empty coarse tiles, [1] sum over them of 4096 x the share of a cosine source's rays
+                            //     that would be loose there: T^2 / (T^2 + travel^2), T the tile's largest fine thickness
 };
 
 // Height field over the source plane (vr_setup.hip: height_field_kernel): per tile of side `tile` the highest point —
