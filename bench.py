@@ -626,7 +626,7 @@ class StubShard:
         self.n = n
         self.last_info = None
 
-    def trace_local(self, first, count, run_number=None):
+    def trace_local(self, first, count, run_number=None, world=1):
         import torch
         idx = (np.arange(first, first + count, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(self.n)
         acc = np.bincount(idx.astype(np.int64), minlength=self.n).astype(np.int64) << 40

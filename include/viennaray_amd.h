@@ -176,6 +176,13 @@ int vr_get_run_number(const vr_context *ctx, uint32_t *runNumber);
  * stays global, so the union over ranks reproduces the single-device stream
  * (rayTraceKernel.hpp:118-121).                                             */
 int vr_set_ray_range(vr_context *ctx, uint64_t first, uint64_t count);
+/* Number of ranks whose flux accumulators the caller is going to SUM (default 1; vr_apply_sharded sets it by itself).
+ * The accumulators are int64 fixed point (weight * 2^VR_FLUX_FRAC_BITS): one primitive and data label holds
+ * 2^23 = 8.39e6 weight units per apply(), divided by `world` rounded up to a power of two so that the signed sum over
+ * the ranks cannot wrap either.  Beyond that vr_apply_finish / vr_apply FAILS (VR_E_STATE, TraceInfo.error = 1,
+ * "flux accumulator overflow") instead of returning wrapped flux — the reference's float sums (rayTraceKernel.hpp:
+ * 348-360, rayParticle.hpp:148-156) stall near 2^24 at that point.                                                  */
+int vr_set_world_size(vr_context *ctx, uint32_t world);
 
 /* Not in the reference (its ray loop allocates nothing per apply): apply() once per time step with a ray
  * count that follows the moving surface re-sizes the HBM ray stream; reserve it for the largest count

@@ -26,7 +26,7 @@ class OracleShard:
         self.o.set_rng_seed(77)
         self.o.set_lazy_rng(True)
 
-    def trace_local(self, first, count, run_number=None):
+    def trace_local(self, first, count, run_number=None, world=1):
         self.o.set_run_number(1 if run_number is None else run_number)
         if count == 0:
             n = self.o.n

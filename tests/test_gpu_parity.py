@@ -2344,3 +2344,45 @@ def test_apply_sharded_over_rccl_two_ranks(tmp_path):
     whole = t.getFluxF64()
     for r in range(2):
         assert (np.load(str(tmp_path / "flux") + f"{r}.npy") == whole).all()
+
+
+def test_accumulator_overflow_is_detected_not_wrapped():
+    """The flux accumulators are int64 fixed point (2^-40 per unit): 2^23 = 8.39e6 weight units per primitive and label in
+    one apply() (signed, so that the multi-GPU all-reduce cannot wrap either).  The reference's float sums stall near 2^24
+    (rayParticle.hpp:148-156, rayTraceKernel.hpp:348-360); these would WRAP — so the apply fails with a message instead.
+    A 4-disk plane: 5e7 absorbing rays put ~3e7 units on every disk -> error; 1e7 rays stay below the limit and are
+    bit-exact against the oracle; with room left for 4 ranks' sum (vr_set_world_size) the same 1e7 rays are refused."""
+    pts, nrm = vr.io.plane_grid(2, 1.0)
+
+    def tracer(rays):
+        t = vr.TraceDisk(3)
+        t.setGeometry(pts, nrm, 1.0)
+        t.setBoundaryConditions([BC.PERIODIC_BOUNDARY] * 3)
+        t.setParticleType(vr.DiffuseParticle(1.0, "flux"))
+        t.setNumberOfRaysFixed(rays)
+        t.setRngSeed(5)
+        return t
+
+    t = tracer(50_000_000)
+    with pytest.raises(vr.VrError, match="flux accumulator overflow"):
+        t.apply()
+    assert t.getRayTraceInfo().error == 1
+    assert t.getRunNumber() == 2            # (the apply counted: the next one uses the next seed, like after any apply)
+    t = tracer(10_000_000)
+    t.apply()
+    f = t.getFluxF64()
+    assert f.max() < 2.0 ** 23 and f.max() > 2.0 ** 22   # just below the limit
+    o = po.Oracle()
+    o.set_disks(pts, nrm, 1.0, 3)
+    o.set_boundary_conditions([po.PERIODIC] * 3)
+    o.set_particle(po.DIFFUSE, 1.0)
+    o.set_num_rays_fixed(10_000_000)
+    o.set_rng_seed(5)
+    o.set_lazy_rng(True)
+    o.apply(po.max_threads())
+    assert (f == o.flux().astype(np.float64)).all()       # integers below 2^24: the oracle's float sums are exact too
+    assert info_dict(t)["geometryHits"] == o.info()["geometryHits"]
+    t = tracer(10_000_000)
+    t.setWorldSize(4)
+    with pytest.raises(vr.VrError, match="flux accumulator overflow"):
+        t.apply()

@@ -78,6 +78,7 @@ SIGNATURES = {
     "vr_set_run_number": (C.c_int, [_vp, C.c_uint32]),
     "vr_get_run_number": (C.c_int, [_vp, _u32p]),
     "vr_set_ray_range": (C.c_int, [_vp, C.c_uint64, C.c_uint64]),
+    "vr_set_world_size": (C.c_int, [_vp, C.c_uint32]),
     "vr_apply": (C.c_int, [_vp]),
     "vr_apply_prepare": (C.c_int, [_vp]),
     "vr_apply_launch": (C.c_int, [_vp]),

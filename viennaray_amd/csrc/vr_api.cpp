@@ -256,6 +256,7 @@ struct vr_context {
   std::vector<hipEvent_t> evG; // generator event pairs, one per batch
   double traceKernelSeconds = 0.0;
   bool havePrimSticking = false;
+  uint32_t worldSize = 1;     // ranks whose accumulators will be summed (vr_set_world_size): head-room of the overflow check
   unsigned long long *boundFlux = nullptr; // caller-owned accumulator buffer
   uint32_t boundFluxN = 0;
   unsigned long long *fluxOut() { return boundFlux ? boundFlux : dFluxOrig.p; }
@@ -761,6 +762,13 @@ int vr_set_run_number(vr_context *c, uint32_t r) {
   c->runNumber = r;
   return VR_OK;
 }
+int vr_set_world_size(vr_context *c, uint32_t world) {
+  if (!c || world == 0 || world > (1u << 20))
+    return fail(c, VR_E_INVALID, "vr_set_world_size: 1 .. 2^20 ranks");
+  c->worldSize = world;
+  return VR_OK;
+}
+
 int vr_set_ray_range(vr_context *c, uint64_t first, uint64_t count) {
   if (!c)
     return VR_E_INVALID;
@@ -1991,9 +1999,14 @@ int vr_apply_launch(vr_context *c) {
         return r;
     }
   VR_HIP(c, hipEventRecord(c->ev1, c->stream));
-  for (uint32_t l = 0; l < c->totalData; ++l)
-    VR_HIP(c, launch_gather_flux(c->dFluxAcc.p + (size_t)l * c->accStride * c->accReplicas, c->accStride, c->accReplicas,
-                                 c->dLeafOfOrig.p, N, c->fluxOut() + (size_t)l * N, c->stream));
+  {
+    unsigned headroom = 0; // the sums of `worldSize` ranks must still fit a signed int64 (vr_set_world_size)
+    while ((1u << headroom) < c->worldSize)
+      ++headroom;
+    for (uint32_t l = 0; l < c->totalData; ++l)
+      VR_HIP(c, launch_gather_flux(c->dFluxAcc.p + (size_t)l * c->accStride * c->accReplicas, c->accStride, c->accReplicas,
+                                   c->dLeafOfOrig.p, N, c->fluxOut() + (size_t)l * N, headroom, c->dCounters.p + 61, c->stream));
+  }
   c->launched = true;
   return VR_OK;
 }
@@ -2044,6 +2057,18 @@ int vr_apply_finish(vr_context *c) {
         std::fprintf(stderr, "phase %-24s %5.1f %% of wave time\n", pn[k], 100.0 * (double)ph[k] / tot);
   }
 #endif
+  // A flux accumulator ran out of range (gather_flux_kernel): 2^23 = 8.39e6 weight units per primitive and data label
+  // in one apply() — divided by the rank count rounded up to a power of two — is what int64 at 2^-40 holds (signed: the
+  // multi-GPU all-reduce).  The reference's float sums stall near 2^24; these would wrap: the apply fails instead.
+  if (all[61]) {
+    c->launched = false;
+    c->prepared = false;
+    c->info.error = 1;
+    ++c->runNumber; // (the apply happened, like one that ends in the reference's error flag: the seeds move on)
+    return fail(c, VR_E_STATE, "flux accumulator overflow: a primitive collected more than 2^23 (8.39e6) weight units per rank-power-of-two "
+                               "in one apply() (int64 fixed point, 2^-40 per unit) - result discarded; trace fewer rays per apply() "
+                               "and sum the normalised results");
+  }
   for (size_t q = 0; q < nPart; ++q) {
     // the walk's stack ran out (a tree deeper than SD + VR_STACK_GLOBAL levels of deferred children): the
     // result would be wrong, so the apply fails
@@ -2252,6 +2277,8 @@ int vr_apply_sharded(vr_context *c, int rank, int world, vr_allreduce_fn reduce,
     c->keepSharedSeed = true; // (cleared below, after the launch)
   }
   int r = VR_OK;
+  const uint32_t worldBefore = c->worldSize;
+  c->worldSize = std::max<uint32_t>(c->worldSize, (uint32_t)world); // (head-room of the overflow check: the sums of all ranks fit int64)
   if (last > first) {
     c->rayFirst = first;
     c->rayCount = last - first;
@@ -2277,6 +2304,7 @@ int vr_apply_sharded(vr_context *c, int rank, int world, vr_allreduce_fn reduce,
   c->rayCount = 0;
   c->haveSharedSeed = false;
   c->keepSharedSeed = false;
+  c->worldSize = worldBefore;
   if (world > 1) {
     // A rank that failed above still enters the collectives when it can (zeros and a raised failure word) —
     // the others would hang in them otherwise.  The TraceInfo counters [0..7] AND the failure word [60] (the

@@ -34,7 +34,8 @@ hipError_t launch_quantize_nodes(const float *nodes, unsigned numNodes, const fl
                                  uint32_t *qnodes, uint32_t *pnodes, hipStream_t st);
 hipError_t launch_setup_neighbors(const SetupParams &s, int pass, hipStream_t st);
 hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, unsigned replicas,
-                              const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, hipStream_t s);
+                              const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, unsigned headroomBits,
+                              unsigned long long *overflowFlag, hipStream_t s);
 
 // 64-ary box tree for the packet query (vr_setup.hip)
 size_t wide_tree_entries(unsigned n);

@@ -1680,23 +1680,37 @@ hipError_t launch_debug_rng(unsigned seed32, unsigned count, unsigned long long 
   return hipGetLastError();
 }
 
-// un-permute the leaf-ordered accumulators into the caller's primitive order
+// un-permute the leaf-ordered accumulators into the caller's primitive order.
+// Overflow is DETECTED, never silent: the accumulators are 64-bit fixed point (2^-40 per unit), summed over the replicas
+// here and — as SIGNED int64 — over the ranks of a multi-GPU apply afterwards.  A primitive's sum must therefore stay
+// below 2^(63 - headroomBits) (headroomBits = ceil(log2(ranks))): a replica with its top bit set, a carry out of the
+// replica sum or a sum at or beyond that bound raises *overflowFlag, and vr_apply_finish fails the apply.
 __global__ void gather_flux_kernel(const unsigned long long *acc, unsigned stride, unsigned replicas,
-                                   const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc) {
+                                   const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, unsigned headroomBits,
+                                   unsigned long long *overflowFlag) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const unsigned q = leafOfOrig[i];
     unsigned long long s = 0; // (integer sum: replica order is irrelevant)
-    for (unsigned r = 0; r < replicas; ++r)
-      s += acc[(size_t)r * stride + q];
+    bool bad = false;
+    for (unsigned r = 0; r < replicas; ++r) {
+      const unsigned long long v = acc[(size_t)r * stride + q];
+      bad = bad || (v >> 63) != 0ull;
+      s += v;
+      bad = bad || s < v; // carry out of 64 bits
+    }
+    bad = bad || (s >> (63u - headroomBits)) != 0ull;
     outAcc[i] = s;
+    if (bad)
+      *overflowFlag = 1ull;
   }
 }
 
 hipError_t launch_gather_flux(const unsigned long long *acc, unsigned stride, unsigned replicas,
-                              const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, hipStream_t s) {
+                              const unsigned *leafOfOrig, unsigned n, unsigned long long *outAcc, unsigned headroomBits,
+                              unsigned long long *overflowFlag, hipStream_t s) {
   hipLaunchKernelGGL(gather_flux_kernel, dim3((n + 255) / 256), dim3(256), 0, s, acc, stride, replicas, leafOfOrig, n,
-                     outAcc);
+                     outAcc, headroomBits, overflowFlag);
   return hipGetLastError();
 }
 

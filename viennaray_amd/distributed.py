@@ -9,7 +9,7 @@ index ranges traced on different devices and summed reproduce the single-device
 result; with the int64 fixed-point accumulators the sum is exact, independent of
 rank count and order.
 
-The shard objects are duck-typed (`trace_local(first, count) -> (acc, counters)`)
+The shard objects are duck-typed (`trace_local(first, count, run_number, world=) -> (acc, counters)`)
 so the same driver runs on the HIP tracer (GpuShard) and, in the CPU `gloo`
 tests, on a stand-in backend.
 """
@@ -47,8 +47,9 @@ class GpuShard:
             self.acc = torch.zeros(n, dtype=torch.int64, device=self.device)
         self.tr.bindFluxAccumulators(self.acc.data_ptr(), n)
 
-    def trace_local(self, first, count, run_number=None):
-        import torch
+    def trace_local(self, first, count, run_number=None, world=1):
+        if hasattr(self.tr, "setWorldSize"):
+            self.tr.setWorldSize(max(1, int(world)))  # (the overflow check leaves room for the sum over the ranks)
         if run_number is not None:
             self.tr.setRunNumber(run_number)
         self._bind()
@@ -79,7 +80,7 @@ def distributed_apply(shard, num_rays, rank=None, world=None, group=None, run_nu
     if rank is None:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     first, count = ray_shard(num_rays, rank, world)
-    acc, cnt = shard.trace_local(first, count, run_number)
+    acc, cnt = shard.trace_local(first, count, run_number, world=world)
     if world > 1:
         import torch
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # exact: integers

@@ -439,6 +439,10 @@ class Trace:
     def setRayRange(self, first, count):
         self._check(self._L.vr_set_ray_range(self._h, int(first), int(count)))
 
+    def setWorldSize(self, world):
+        """Ranks whose accumulators will be summed: head-room of the accumulator-overflow check (vr_set_world_size)."""
+        self._check(self._L.vr_set_world_size(self._h, int(world)))
+
     # --- run ---------------------------------------------------------------
     def apply(self):
         if self._particle is None:
