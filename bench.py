@@ -280,6 +280,57 @@ def secondary_case(name, rays, sample, threads, sticking=None, reps=2, ray_range
     return out
 
 
+def make_step(tr, shard, total_rays, rank, world):
+    """One step of the headline workload.  N = 1: the reference's whole apply() — generator, trace, gather AND the float
+    flux in the host's TracingData (rayTraceDisk.hpp:40-57, rayTrace.hpp:135): `tr.apply()`, download inside the timer.
+    N > 1: this rank's shard, then ONE all-reduce of the int64 accumulators, which stay on the device (the collective
+    needs them there; every rank ends with the full sums).  Returns (step, end_state); step() -> (info, counters)."""
+    from viennaray_amd import distributed as vd
+    if world == 1:
+        def step():
+            tr.setRunNumber(1)   # every step traces the same seeded stream (runNumber 1 -> kernel seed 12346)
+            tr.setRayRange(0, 0)
+            tr.apply()
+            return tr.getRayTraceInfo(), {"allreduce_ms": 0.0}
+        return step, "float flux in the host's TracingData (vr_get_flux_data inside the timed step)"
+
+    def step():
+        # rank r traces its contiguous slice of the global ray indices (SURVEY §8e), then ONE
+        # RCCL all-reduce of the int64 flux accumulators (+ the 7 counters)
+        acc, counters = vd.distributed_apply(shard, total_rays, rank, world, run_number=1)
+        return shard.last_info, counters
+    return step, "int64 accumulators on every device, all-reduced (no host download inside the step)"
+
+
+def secondary_failures(sec):
+    """Names of the secondary workloads that raised, or whose parity sample disagrees with the oracle (any counter, or
+    flux L2 > 1e-4): a broken BASELINE config must be visible in the exit code, not only inside the JSON line."""
+    bad = []
+    for r in sec or []:
+        if "error" in r:
+            bad.append(f"{r.get('name')}: {r['error']}")
+        elif any(v != 0 for v in (r.get("counter_diff") or {}).values()):
+            bad.append(f"{r.get('name')}: counters differ {r['counter_diff']}")
+        elif r.get("flux_l2_rel_err") is not None and not (r["flux_l2_rel_err"] <= 1e-4):
+            bad.append(f"{r.get('name')}: flux L2-rel-err {r['flux_l2_rel_err']}")
+    return bad
+
+
+def emit(out):
+    """Print THE json line; return the exit code: 0, or 3 when a parity check of the line failed (headline sample or any
+    secondary) — after the line, so the record stays intact."""
+    failed = secondary_failures(out.get("secondary"))
+    if any(v != 0 for v in (out.get("counter_diff") or {}).values()) or \
+            (out.get("flux_l2_rel_err") is not None and not out["flux_l2_rel_err"] <= 1e-4):
+        failed.insert(0, "headline parity sample")
+    if failed:
+        out["parity_failed"] = failed
+    print(json.dumps(out), flush=True)
+    if failed:
+        print("bench.py: a parity check failed: " + "; ".join(failed), file=sys.stderr, flush=True)
+    return 3 if failed else 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +347,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--stub-shard", action="store_true",
                     help="CPU rehearsal of the multi-rank path (tests): a deterministic stand-in shard, gloo")
+    ap.add_argument("--stub-secondary-error", action="store_true",
+                    help="(tests, with --stub-shard) a secondary workload that raised: the line is printed, the exit code is 3")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -351,20 +404,14 @@ def main():
     tr.setParticleType(vr.DiffuseParticle(args.sticking, "flux"))
     tr.setRngSeed(seed)
     tr.setNumberOfRaysFixed(total_rays)
-    shard = vd.GpuShard(tr, dev)  # binds a torch int64 accumulator tensor
+    shard = vd.GpuShard(tr, dev) if world > 1 else None  # (binds a torch int64 accumulator tensor: what RCCL reduces)
 
     t0 = time.perf_counter()
     tr.applyPrepare()  # bbox, walls, areas, LBVH, uploads: geometry resident in HBM
     build_s = time.perf_counter() - t0
 
-    pipe_ms, trace_ms, gen_ms, segs, geo = [], [], [], [], []
-
-    def step():
-        # rank r traces its contiguous slice of the global ray indices, then ONE
-        # RCCL all-reduce of the int64 flux accumulators (+ the 7 counters).  Every
-        # step traces the same seeded stream (runNumber 1 -> kernel seed 12346).
-        acc, counters = vd.distributed_apply(shard, total_rays, rank, world, run_number=1)
-        return shard.last_info, counters
+    pipe_ms, trace_ms, gen_ms, segs, geo, wall_ms, ar_ms = [], [], [], [], [], [], []
+    step, end_state = make_step(tr, shard, total_rays, rank, world)
 
     def sync_all():
         if distributed:
@@ -376,7 +423,10 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        info, _ = step()
+        ts = time.perf_counter()
+        info, cnts = step()
+        wall_ms.append((time.perf_counter() - ts) * 1e3)
+        ar_ms.append(float(cnts.get("allreduce_ms", 0.0)))
         if info is not None:
             pipe_ms.append(info.timeTrace * 1e3)
             trace_ms.append(info.timeTraceKernel * 1e3)
@@ -390,6 +440,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # per-rank spread of the step (outside the timed region): a measured N > 1 curve must be attributable
+    per_rank = vd.rank_report([rank, np.mean(trace_ms) if trace_ms else 0.0, np.mean(gen_ms) if gen_ms else 0.0,
+                               np.mean(pipe_ms) if pipe_ms else 0.0, np.mean(ar_ms) if ar_ms else 0.0,
+                               np.mean(wall_ms) if wall_ms else 0.0, rays_rank]) if distributed else None
     if rank == 0:
         mode = tr.traceMode()
         kernel_name = f"trace_kernel<3,0,{0 if mode in (1, 2) else tr._particle.kind},{mode}>"
@@ -423,15 +477,29 @@ def main():
                        "kernel_mode": {0: "general (reflection + roulette + RNG)", 1: "absorbing, flat scene",
                                        2: "absorbing, structured scene",
                                        3: "general, flat scene (packet-query crediting)",
-                                       4: "general, scene resident in LDS"}.get(mode, str(mode)),
+                                       4: "general, scene resident in LDS",
+                                       5: "absorbing, flat with relief (relief packets + loose bins)",
+                                       6: "general, flat with relief (relief packets + loose bins)"}.get(mode, str(mode)),
                        "parallelism": f"ray-range shards x{world}, BVH replicated, int64 flux all-reduce"},
             "device_pipeline_ms": round(kavg, 4), "trace_kernel_ms": round(tavg, 4), "gen_kernel_ms": round(gavg, 4),
+            "apply_wall_ms": round(float(np.mean(wall_ms)), 4), "end_state": end_state,
             "segments_per_step": int(np.mean(segs)), "Msegments_per_s": round(np.mean(segs) / (kavg * 1e-3) / 1e6, 2),
             "trace_launches_per_step": int(math.ceil(rays_rank / float(1 << 27))),  # one per batch of <= 2^27 rays
             "prepare_s": round(build_s, 4), "lib_sha256": sha[:16],
             "bvh_refits": int(info.bvhRefits) if info is not None else None,  # (0: the BVH fit's fast hand-over never needed its fenced retry)
             "roofline": roof,
         }
+        if per_rank is not None:
+            cols = ("rank", "trace_ms", "gen_ms", "device_pipeline_ms", "allreduce_ms", "step_wall_ms", "rays")
+            out["multi_gpu"] = {
+                "rccl_ranks_seen": len(per_rank), "backend": args.backend,
+                "allreduce_ms": round(float(np.mean(ar_ms)), 4),
+                "allreduce_ms_max_over_ranks": round(max(r[4] for r in per_rank), 4),
+                "trace_ms_min": round(min(r[1] for r in per_rank), 4), "trace_ms_max": round(max(r[1] for r in per_rank), 4),
+                "step_wall_ms_min": round(min(r[5] for r in per_rank), 4), "step_wall_ms_max": round(max(r[5] for r in per_rank), 4),
+                "per_rank": [dict(zip(cols, [int(r[0])] + [round(v, 4) for v in r[1:6]] + [int(r[6])])) for r in per_rank],
+                "note": "allreduce_ms: HIP events round the two collectives of a step (int64 flux + counters) on this rank; "
+                        "a rank that finishes its shard early waits inside the collective for the slowest one"}
         if world == 1:
             from oracle import pyoracle as po  # the checker / CPU baseline only (never the product path)
             threads = min(po.max_threads(), host_cpu_share())
@@ -439,7 +507,6 @@ def main():
             #      (the reference's TraceInfo.time includes the build) -------------------
             t0 = time.perf_counter()
             tr.setGeometry(pts, nrm, 1.0)
-            shard._bind()
             tr.setRunNumber(1)
             tr.setRayRange(0, 0)
             tr.applyPrepare()
@@ -498,13 +565,17 @@ def main():
                         if label:
                             r["name"] = label
                         sec.append(r)
-                    except Exception as e:  # a failing secondary must not hide the headline
+                    except Exception as e:  # a failing secondary must not hide the headline ...
                         sec.append(dict(name=label or cs["name"], error=str(e)))
-                out["secondary"] = sec
-        print(json.dumps(out))
+                out["secondary"] = sec  # ... but it must show in the exit code (emit: after the JSON line)
+        exit_code = emit(out)
+    else:
+        exit_code = 0
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 ISSUE_CLASSES = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS")
@@ -642,24 +713,44 @@ def stub_main(args, rank, world, total_rays):
     if "RANK" in os.environ:
         dist.init_process_group("gloo")
     shard = StubShard(args.grid * args.grid)
+    ar_ms, wall_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         acc, counters = vd.distributed_apply(shard, total_rays, rank, world, run_number=1)
+        wall_ms.append((time.perf_counter() - ts) * 1e3)
+        ar_ms.append(counters.pop("allreduce_ms", 0.0))
     elapsed = time.perf_counter() - t0
+    # the keys of the real line's `multi_gpu` block (the stand-in has no kernels: its trace time is wall - all-reduce)
+    per_rank = vd.rank_report([rank, np.mean(wall_ms) - np.mean(ar_ms), 0.0, 0.0, np.mean(ar_ms), np.mean(wall_ms),
+                               vd.ray_shard(total_rays, rank, world)[1]])
     if dist.is_initialized():
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    exit_code = 0
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": total_rays * args.steps / elapsed / 1e6, "unit": "Mrays/s",
+        out = ({"metric": "stub", "value": total_rays * args.steps / elapsed / 1e6, "unit": "Mrays/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "scaling": "strong" if args.total_rays > 0 else "weak", "total_rays": total_rays,
                           "acc_sum": int(acc.sum().item() >> 40), "acc_checksum": int((acc >> 40).numpy().dot(
                               np.arange(acc.numel(), dtype=np.int64) % 1000003) % (1 << 61)),
-                          "counters": counters}))
+                          "counters": counters,
+                          "multi_gpu": {"rccl_ranks_seen": len(per_rank), "backend": "gloo (stand-in shard)",
+                                        "allreduce_ms": round(float(np.mean(ar_ms)), 4),
+                                        "trace_ms_min": round(min(r[1] for r in per_rank), 4),
+                                        "trace_ms_max": round(max(r[1] for r in per_rank), 4),
+                                        "per_rank": [dict(rank=int(r[0]), trace_ms=round(r[1], 4), allreduce_ms=round(r[4], 4),
+                                                          step_wall_ms=round(r[5], 4), rays=int(r[6])) for r in per_rank]}})
+        if args.stub_secondary_error:
+            out["secondary"] = [dict(name="stub_ok", counter_diff={"geometryHits": 0}, flux_l2_rel_err=0.0),
+                                dict(name="stub_broken", error="injected failure")]
+        exit_code = emit(out)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

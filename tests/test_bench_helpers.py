@@ -41,3 +41,36 @@ def test_roofline_block_is_counter_bytes_over_time_over_peak():
     assert abs(r["wave_instr_per_segment"] - 51.7) < 0.1
     assert r["useful_lane_frac"] == 0.34 and r["l2_hit_rate"] == 0.74 and r["wait_frac"] == 0.52
     assert "issue_diag" in r and "frac" not in r["issue_diag"]
+
+
+def test_single_gpu_step_ends_with_the_flux_on_the_host():
+    """N = 1: a timed step is the reference's whole apply() — through the float flux in the host's TracingData
+    (rayTraceDisk.hpp:40-57, rayTrace.hpp:135) — i.e. `Trace.apply()`, which downloads; N > 1: the shard + all-reduce on
+    the device-resident accumulators (round-3 verdict, item 3)."""
+    b = _bench()
+    calls = []
+
+    class FakeTracer:
+        def setRunNumber(self, n): calls.append(("run", n))
+        def setRayRange(self, a, c): calls.append(("range", a, c))
+        def apply(self): calls.append(("apply",))            # vr_apply + the download into TracingData
+        def applyFinish(self, collect=True): calls.append(("finish", collect))
+        def getRayTraceInfo(self): return "info"
+
+    step, end_state = b.make_step(FakeTracer(), None, 1000, 0, 1)
+    info, counters = step()
+    assert ("apply",) in calls and not any(c[0] == "finish" for c in calls)
+    assert info == "info" and counters["allreduce_ms"] == 0.0 and "host" in end_state
+
+    shard = b.StubShard(100)
+    step, end_state = b.make_step(None, shard, 1000, 0, 2)   # (world 2 without a process group: never called here)
+    assert "device" in end_state
+
+
+def test_a_failing_secondary_shows_in_the_exit_code():
+    b = _bench()
+    ok = dict(name="C4", counter_diff={"totalRaysTraced": 0, "geometryHits": 0}, flux_l2_rel_err=3e-9)
+    assert b.secondary_failures([ok, dict(name="x", rays=1)]) == []
+    bad = b.secondary_failures([ok, dict(name="C5p", error="boom"), dict(name="C2", counter_diff={"geometryHits": 1}, flux_l2_rel_err=0.0),
+                                dict(name="C1", counter_diff={"geometryHits": 0}, flux_l2_rel_err=2e-4)])
+    assert len(bad) == 3 and bad[0].startswith("C5p") and "counters differ" in bad[1] and "flux" in bad[2]

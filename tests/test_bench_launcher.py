@@ -54,6 +54,13 @@ def test_eight_ranks_strong_scaling_like_c3():
     assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["total_rays"] == 1000003
     assert (out["acc_sum"], out["acc_checksum"]) == _expected(1000003, 2500)
     assert out["counters"]["totalRaysTraced"] == 1000003
+    # the first measured multi-GPU curve must be attributable: the collective's time, the per-rank spread of the trace
+    # time and the number of ranks that answered travel on the line (round-3 verdict)
+    mg = out["multi_gpu"]
+    assert mg["rccl_ranks_seen"] == 8 and len(mg["per_rank"]) == 8
+    assert sorted(r["rank"] for r in mg["per_rank"]) == list(range(8))
+    assert sum(r["rays"] for r in mg["per_rank"]) == 1000003
+    assert mg["allreduce_ms"] > 0.0 and mg["trace_ms_max"] >= mg["trace_ms_min"] >= 0.0
 
 
 def test_world_size_mismatch_is_an_error():
@@ -61,3 +68,17 @@ def test_world_size_mismatch_is_an_error():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--stub-shard"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_a_failing_secondary_fails_the_run_after_the_json_line():
+    """A secondary workload that raised (or whose parity sample disagrees) must show in bench.py's exit code — with the
+    JSON line printed and intact (round-3 verdict: a broken BASELINE config used to leave a green record)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0", "--stub-shard",
+                        "--grid", "20", "--rays", "1000", "--stub-secondary-error"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-500:])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["parity_failed"] == ["stub_broken: injected failure"]
+    assert "parity check failed" in p.stderr

@@ -81,19 +81,51 @@ def distributed_apply(shard, num_rays, rank=None, world=None, group=None, run_nu
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     first, count = ray_shard(num_rays, rank, world)
     acc, cnt = shard.trace_local(first, count, run_number, world=world)
+    allreduce_ms = 0.0
     if world > 1:
+        import time
         import torch
+        # the collective's time as the stream sees it (HIP events round it: backend "nccl" = RCCL over xGMI; CPU tensors
+        # of the gloo rehearsal: wall clock) — so that a measured multi-GPU step can be split into trace + all-reduce
+        on_gpu = bool(getattr(acc, "is_cuda", False))
+        if on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        else:
+            t0 = time.perf_counter()
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # exact: integers
         # (the counters travel as a device tensor only when there is something to reduce: a single rank keeps
         #  them on the host and saves two trips over PCIe per apply)
         cnt_t = cnt if torch.is_tensor(cnt) else torch.tensor(cnt, dtype=torch.int64, device=acc.device)
         dist.all_reduce(cnt_t, op=dist.ReduceOp.SUM, group=group)
         cnt = cnt_t
+        if on_gpu:
+            e1.record()
+            e1.synchronize()
+            allreduce_ms = float(e0.elapsed_time(e1))
+        else:
+            allreduce_ms = (time.perf_counter() - t0) * 1e3
     if hasattr(cnt, "tolist"):
         cnt = cnt.tolist()
     counters = {k: int(v) for k, v in zip(COUNTER_KEYS, cnt)}
     counters["numRays"] = int(num_rays)
+    counters["allreduce_ms"] = allreduce_ms
     return acc, counters
+
+
+def rank_report(values, group=None):
+    """Every rank's row of floats gathered on all ranks (outside any timed region): the per-rank spread of a multi-GPU
+    step — trace / generator / all-reduce milliseconds — and the number of ranks that answered."""
+    import torch
+    import torch.distributed as dist
+    row = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [row.tolist()]
+    if dist.get_backend(group) == "nccl":
+        row = row.cuda()
+    rows = [torch.zeros_like(row) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(rows, row, group=group)
+    return [r.cpu().tolist() for r in rows]
 
 
 def accumulators_to_flux(acc):
