@@ -249,7 +249,10 @@ int vr_get_neighbor_counts(vr_context *ctx, uint32_t *out, uint32_t n);
 int vr_flux_accumulators(vr_context *ctx, void **devPtr, uint32_t *n);
 /* Let the caller own the accumulator buffer instead (e.g. a torch int64 tensor
  * handed to torch.distributed/RCCL): DEVICE pointer to n int64; NULL restores
- * the library-owned buffer.  Must stay valid until replaced.                  */
+ * the library-owned buffer.  Must stay valid until replaced.  The binding survives
+ * vr_set_particle(s) as long as numPrims x data labels is unchanged; a call that changes the
+ * number of data labels, and vr_set_disks / vr_set_triangles, drop it (the library's own
+ * buffer is used again: bind anew).                                          */
 int vr_bind_flux_accumulators(vr_context *ctx, void *devPtr, uint32_t n);
 int vr_add_trace_info(vr_context *ctx, const vr_trace_info *other);
 /* stream the context launches on (hipStream_t as void*)                      */

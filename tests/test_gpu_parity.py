@@ -1905,6 +1905,45 @@ def test_particle_model_that_does_not_compile_is_refused(tmp_path, monkeypatch):
         t.setParticleType(vr.UserModelParticle(1000, 0.5, ["x"]))
 
 
+def test_run_time_model_cache_and_sources_are_checked(tmp_path, monkeypatch):
+    """The code-object cache holds code that hipModuleLoad runs: a directory that is not the caller's own with mode 0700
+    is refused (another local user could have planted a code object under a predictable name).  And a model is compiled
+    only from the kernel sources THIS library was built from — its kernels take the library's TraceParams by value, so
+    sources with another layout would end in a GPU memory fault, not in an error code (round-3 advisor)."""
+    import shutil
+    import stat
+    model = "struct VrUserModel : ModelDiffuse {};"
+    t = vr.TraceDisk(3)
+    open_dir = tmp_path / "shared_cache"
+    open_dir.mkdir()
+    os.chmod(open_dir, 0o755)
+    monkeypatch.setenv("VR_CACHE_DIR", str(open_dir))
+    with pytest.raises(vr.VrError, match="mode 0700"):
+        t.registerParticleModel(model, numData=1)
+    link = tmp_path / "link_cache"
+    private = tmp_path / "private_cache"
+    private.mkdir(mode=0o700)
+    os.symlink(private, link)
+    monkeypatch.setenv("VR_CACHE_DIR", str(link))
+    with pytest.raises(vr.VrError, match="symbolic link"):
+        t.registerParticleModel(model, numData=1)
+    # kernel sources that differ from the library's own
+    monkeypatch.setenv("VR_CACHE_DIR", str(private))
+    src = os.path.join(os.path.dirname(vr.LIB_PATH), "csrc")
+    other = tmp_path / "csrc"
+    other.mkdir()
+    for fn in os.listdir(src):
+        if fn.endswith((".hip", ".hpp")):
+            shutil.copy(os.path.join(src, fn), other / fn)
+    with open(other / "vr_types.hpp", "a") as fh:
+        fh.write("\n// edited after the library was built\n")
+    monkeypatch.setenv("VR_CSRC_DIR", str(other))
+    with pytest.raises(vr.VrError, match="not the ones this library was built from"):
+        t.registerParticleModel(model, numData=1)
+    assert not [f for f in os.listdir(private) if f.endswith(".hsaco")]
+    assert stat.S_IMODE(os.stat(private).st_mode) == 0o700
+
+
 @pytest.mark.parametrize("n,flat", [(21, "1"), (21, "0"), (100, "0"), (8, "1")])
 def test_two_label_particle_on_coarse_planes_matches_oracle(n, flat, monkeypatch):
     """Coarse flat scenes are where a wave's credits pile up on a few disks (merged per disk and weight, or summed over the

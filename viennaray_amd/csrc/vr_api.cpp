@@ -488,7 +488,12 @@ int vr_set_particles(vr_context *c, const vr_particle *list, uint32_t n) {
   c->totalData = total;
   c->dataBase = 0;
   c->counterSlot = 0;
-  c->boundFlux = nullptr; // (the number of planes may have changed)
+  // a caller's accumulator buffer (vr_bind_flux_accumulators) stays bound while it still has the right size: numPrims x
+  // data labels of ALL particles; it is dropped only when the number of planes changed
+  if (c->boundFlux && c->boundFluxN != c->geo.numPrims * total) {
+    c->boundFlux = nullptr;
+    c->boundFluxN = 0;
+  }
   c->haveParticle = true;
   c->prepared = false;
   return VR_OK;
@@ -529,6 +534,44 @@ static std::string csrc_dir() {
   return "csrc";
 }
 
+// POSIX cksum (CRC-32, polynomial 0x04C11DB7, the length appended) of a file's bytes: what the Makefile records of every
+// kernel source at build time (VR_SRC_CKSUM) — a run-time model must be compiled from THOSE sources: its kernels take the
+// library's TraceParams by value.
+static uint32_t posix_cksum(const std::string &data) {
+  static uint32_t table[256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i << 24;
+      for (int k = 0; k < 8; ++k)
+        c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : (c << 1);
+      table[i] = c;
+    }
+    init = true;
+  }
+  uint32_t crc = 0;
+  for (unsigned char b : data)
+    crc = (crc << 8) ^ table[((crc >> 24) ^ b) & 0xFFu];
+  for (size_t n = data.size(); n; n >>= 8)
+    crc = (crc << 8) ^ table[((crc >> 24) ^ (n & 0xFFu)) & 0xFFu];
+  return ~crc;
+}
+
+// the compiler's identity (`hipcc --version`, first lines), part of the cache key: a code object does not survive a
+// toolchain upgrade
+static std::string compiler_identity(const std::string &hipcc) {
+  std::string out;
+  if (hipcc.find('\'') != std::string::npos)
+    return out;
+  if (FILE *f = popen(("'" + hipcc + "' --version 2>/dev/null").c_str(), "r")) {
+    char buf[256];
+    while (out.size() < 2048 && std::fgets(buf, sizeof(buf), f))
+      out += buf;
+    pclose(f);
+  }
+  return out;
+}
+
 // The reference's GPU path registers user callables per particle at run time (gpu/raygCallableConfig.hpp:7-18: OptiX
 // direct callables named in the particle).  Here the caller hands over the SOURCE of a model — `struct VrUserModel` with
 // the registry's shape (vr_particles.hpp: sticking / reflect / collide, kNumData, kNeedsFull), usually a few lines on top of
@@ -540,46 +583,86 @@ int vr_register_particle_model(vr_context *c, const char *name, const char *sour
   VR_HIP(c, hipSetDevice(c->device));
   const std::string csrc = csrc_dir();
   const bool full = (flags & VR_MODEL_NEEDS_FULL) != 0;
+  const std::string hipcc = std::getenv("VR_HIPCC") ? std::getenv("VR_HIPCC") : "/opt/rocm/bin/hipcc";
+  const std::string ccFlags = " --genco --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function";
   uint64_t h = 1469598103934665603ull;
   h = fnv1a(h, source, std::strlen(source));
   h = fnv1a(h, &numData, sizeof(numData));
   h = fnv1a(h, &full, sizeof(full));
+  std::string cksums;
   for (const char *fn : {"vr_trace.hip", "vr_device.hpp", "vr_particles.hpp", "vr_types.hpp", "vr_libm.hpp", "vr_kernels.hpp"}) {
     std::string text;
     if (!slurp(csrc + "/" + fn, text))
       return fail(c, VR_E_STATE, ("vr_register_particle_model: kernel source not found: " + csrc + "/" + fn +
                                   " (the sources ship next to the library; VR_CSRC_DIR overrides)").c_str());
     h = fnv1a(h, text.data(), text.size());
+    cksums += std::to_string(posix_cksum(text)) + "-";
   }
-  std::string cache = "/tmp/viennaray_amd_cache_" + std::to_string((unsigned)getuid());
+#ifdef VR_SRC_CKSUM
+  // The kernels of the module take the library's TraceParams by value and read the LDS frame the host fills: sources that
+  // are not the ones this library was built from (an edited checkout without a rebuild, a wrong VR_CSRC_DIR, an installed
+  // library next to a newer tree) would end in a GPU memory fault, not in an error code.  Refused here.
+  if (cksums != VR_SRC_CKSUM)
+    return fail(c, VR_E_STATE, ("vr_register_particle_model: the kernel sources in " + csrc + " are not the ones this library was built "
+                                "from (checksums " + cksums + " against " VR_SRC_CKSUM "): rebuild the library, or point VR_CSRC_DIR at its sources").c_str());
+#endif
+  { // (a code object does not survive a change of the compiler or of its flags)
+    const std::string id = compiler_identity(hipcc) + ccFlags;
+    h = fnv1a(h, id.data(), id.size());
+  }
+  // The cache holds code that hipModuleLoad will run: a directory of the caller's own, mode 0700, and checked — a
+  // predictable name under /tmp that another local user created first could hold a planted code object.
+  std::string cache;
   if (const char *e = std::getenv("VR_CACHE_DIR"))
     cache = e;
+  else if (const char *x = std::getenv("XDG_CACHE_HOME"); x && *x)
+    cache = std::string(x) + "/viennaray_amd";
+  else if (const char *hm = std::getenv("HOME"); hm && *hm && std::string(hm) != "/") {
+    (void)mkdir((std::string(hm) + "/.cache").c_str(), 0700);
+    cache = std::string(hm) + "/.cache/viennaray_amd";
+  } else
+    cache = "/tmp/viennaray_amd_cache_" + std::to_string((unsigned)getuid());
   (void)mkdir(cache.c_str(), 0700);
+  {
+    struct stat ds;
+    if (lstat(cache.c_str(), &ds) != 0 || !S_ISDIR(ds.st_mode) || ds.st_uid != getuid() || (ds.st_mode & 077) != 0)
+      return fail(c, VR_E_STATE, ("vr_register_particle_model: the code-object cache " + cache + " must be a directory (no symbolic link) "
+                                  "owned by this user with mode 0700 - refused; set VR_CACHE_DIR to a private directory").c_str());
+  }
   char hex[32];
   std::snprintf(hex, sizeof(hex), "%016llx", (unsigned long long)h);
   const std::string base = cache + "/model_" + hex, hsaco = base + ".hsaco";
   struct stat st;
   if (stat(hsaco.c_str(), &st) != 0 || st.st_size == 0) {
-    { std::ofstream f(base + "_model.hpp"); f << source << "\n"; }
+    // every file of this compilation under a name of this process's own (several ranks register the same model on a cold
+    // cache at once); the code object then moves into place atomically
+    const std::string mine = base + ".p" + std::to_string((int)getpid());
+    const std::string tmp = mine + ".hsaco";
+    { std::ofstream f(mine + "_model.hpp"); f << source << "\n"; }
     {
-      std::ofstream f(base + ".hip");
+      std::ofstream f(mine + ".hip");
       f << "// generated by vr_register_particle_model\n#define VR_USER_MODULE 1\n#define VR_USER_NUM_DATA " << numData
-        << "\n#define VR_USER_MODEL_FILE \"" << base << "_model.hpp\"\n#include \"" << csrc << "/vr_trace.hip\"\n"
+        << "\n#define VR_USER_MODEL_FILE \"" << mine << "_model.hpp\"\n#include <cstddef>\n#include \"" << csrc << "/vr_trace.hip\"\n"
         << "static_assert(vr::VrUserModel::kNeedsFull == " << (full ? "true" : "false")
-        << ", \"kNeedsFull differs from the VR_MODEL_NEEDS_FULL flag given at registration\");\n";
+        << ", \"kNeedsFull differs from the VR_MODEL_NEEDS_FULL flag given at registration\");\n"
+        // the launch parameters and the LDS frame as THIS library lays them out
+        << "static_assert(sizeof(vr::TraceParams) == " << sizeof(TraceParams) << " && offsetof(vr::TraceParams, globalVec) == "
+        << offsetof(TraceParams, globalVec) << " && offsetof(vr::TraceParams, counters) == " << offsetof(TraceParams, counters)
+        << " && offsetof(vr::TraceParams, reliefLookups) == " << offsetof(TraceParams, reliefLookups) << " && vr::VR_WALL_TABLE == "
+        << VR_WALL_TABLE << ", \"vr::TraceParams / the launch frame differ from the loaded library's: these kernel sources are not its own\");\n";
     }
-    const char *hipcc = std::getenv("VR_HIPCC");
-    const std::string tmp = base + ".tmp" + std::to_string((int)getpid());
     auto quoted = [](const std::string &path) { return "'" + path + "'"; }; // (paths with blanks; a quote in a path is refused below)
-    if ((cache + csrc).find('\'') != std::string::npos)
+    if ((cache + csrc + hipcc).find('\'') != std::string::npos)
       return fail(c, VR_E_INVALID, "vr_register_particle_model: the cache / source directory must not contain a quote character");
-    const std::string cmd = quoted(hipcc ? hipcc : "/opt/rocm/bin/hipcc") +
-                            " --genco --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -I" +
-                            quoted(csrc) + " " + quoted(base + ".hip") + " -o " + quoted(tmp) + " > " + quoted(base + ".log") + " 2>&1";
+    const std::string cmd = quoted(hipcc) + ccFlags + " -I" + quoted(csrc) + " " + quoted(mine + ".hip") + " -o " + quoted(tmp) + " > " +
+                            quoted(mine + ".log") + " 2>&1";
     const int rc = std::system(cmd.c_str());
+    (void)unlink((mine + ".hip").c_str());
+    (void)unlink((mine + "_model.hpp").c_str());
     if (rc != 0) {
       std::string all, log;
-      (void)slurp(base + ".log", all);
+      (void)slurp(mine + ".log", all);
+      (void)std::rename((mine + ".log").c_str(), (base + ".log").c_str()); // (kept for the caller to read)
       { // the compiler's error lines (and the source line under each), not the tail of its output
         std::istringstream in(all);
         std::string line;
@@ -596,6 +679,7 @@ int vr_register_particle_model(vr_context *c, const char *name, const char *sour
       (void)unlink(tmp.c_str());
       return fail(c, VR_E_INVALID, ("vr_register_particle_model: the model did not compile (" + base + ".log):\n" + log).c_str());
     }
+    (void)unlink((mine + ".log").c_str());
     if (std::rename(tmp.c_str(), hsaco.c_str()) != 0)
       return fail(c, VR_E_STATE, "vr_register_particle_model: cannot write the code object cache");
   }

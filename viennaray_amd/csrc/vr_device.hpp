@@ -967,10 +967,11 @@ __device__ __forceinline__ void wave_minmax6(float &a, float &b, float &c, float
 #define VR_DPP6(ctrl)                                                                                                  \
   "v_min_f32_dpp %0, %0, %0 " ctrl "\n v_min_f32_dpp %1, %1, %1 " ctrl "\n v_min_f32_dpp %2, %2, %2 " ctrl "\n"        \
   "v_max_f32_dpp %3, %3, %3 " ctrl "\n v_max_f32_dpp %4, %4, %4 " ctrl "\n v_max_f32_dpp %5, %5, %5 " ctrl "\n"
-  // (s_nop 1: the compiler does not know that the block begins with DPP reads — a VGPR written by the VALU instruction
-  //  just before it needs two wait states before a DPP instruction may read it, and nothing inserts them for inline
-  //  assembly.  Found when a second call site, scheduled differently, returned minima of stale registers now and then)
-  asm volatile("s_nop 1\n" VR_DPP6("row_shr:1 row_mask:0xf bank_mask:0xf") VR_DPP6("row_shr:2 row_mask:0xf bank_mask:0xf")
+  // (s_nop 4: the compiler does not know that the block begins with DPP reads — a VGPR written by the VALU instruction
+  //  just before it needs two wait states before a DPP instruction may read it, a VALU write of EXEC (v_cmpx, v_readlane
+  //  into exec) five, and nothing inserts them for inline assembly.  Found when a second call site, scheduled
+  //  differently, returned minima of stale registers now and then; five wait states cover both hazards of the gfx9 table)
+  asm volatile("s_nop 4\n" VR_DPP6("row_shr:1 row_mask:0xf bank_mask:0xf") VR_DPP6("row_shr:2 row_mask:0xf bank_mask:0xf")
                    VR_DPP6("row_shr:4 row_mask:0xf bank_mask:0xf") VR_DPP6("row_shr:8 row_mask:0xf bank_mask:0xf")
                        VR_DPP6("row_bcast:15 row_mask:0xa bank_mask:0xf") VR_DPP6("row_bcast:31 row_mask:0xc bank_mask:0xf")
                : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));

@@ -337,6 +337,8 @@ class Trace:
         if isinstance(data, TracingData) and data._scalars:
             sc = np.ascontiguousarray(data._scalars, dtype=np.float32)
             self._check(self._L.vr_set_global_scalars(self._h, _fptr(sc), sc.size))
+        else:  # (no scalars in the new data: the previous ones must not linger on the device)
+            self._check(self._L.vr_set_global_scalars(self._h, None, 0))
         self._globalData = data
 
     def getGlobalData(self):
