@@ -712,6 +712,8 @@ RELIEF_KNOBS = [
     {"VR_RELIEF_LOOKUPS": "2"}, {"VR_RELIEF_LOOKUPS": "0"}, {"VR_RELIEF_COARSE_K": "1"},
     {"VR_RAYS_PER_BIN": "3"}, {"VR_BATCH_RAYS": "50000"},
     {"VR_BIN_CAP": "8", "VR_RAYS_PER_BIN": "16"},  # most rays overflow their (tight or loose) bin
+    {"VR_NO_SPILL": "1"}, {"VR_DEBUG_FLAGS": "8192"},  # continuing rays stay in the tight general kernel (no spill queue)
+    {"VR_LOOSE_BLOCKS": "1"},
 ]
 
 

@@ -242,6 +242,8 @@ struct vr_context {
   uint32_t rfBuild = 0xFFFFFFFFu;
   int rfAxes[4] = {-1, -1, -1, -1};
   float rfLooseShare = 1.f;
+  DevBuf<float> dSpillRec;     // the general relief kernel's spill queue (TraceParams::spillRec), 16 floats per ray of a batch
+  DevBuf<uint32_t> dSpillCount;
   bool reliefScene = false;    // the prepared launch: MODE 5 / 6 over the tight bins + looseMode over the loose ones
   int looseMode = 0;
   unsigned looseGrid = 0;
@@ -648,7 +650,7 @@ int vr_register_particle_model(vr_context *c, const char *name, const char *sour
         // the launch parameters and the LDS frame as THIS library lays them out
         << "static_assert(sizeof(vr::TraceParams) == " << sizeof(TraceParams) << " && offsetof(vr::TraceParams, globalVec) == "
         << offsetof(TraceParams, globalVec) << " && offsetof(vr::TraceParams, counters) == " << offsetof(TraceParams, counters)
-        << " && offsetof(vr::TraceParams, reliefLookups) == " << offsetof(TraceParams, reliefLookups) << " && vr::VR_WALL_TABLE == "
+        << " && offsetof(vr::TraceParams, spillCount) == " << offsetof(TraceParams, spillCount) << " && vr::VR_WALL_TABLE == "
         << VR_WALL_TABLE << ", \"vr::TraceParams / the launch frame differ from the loaded library's: these kernel sources are not its own\");\n";
     }
     auto quoted = [](const std::string &path) { return "'" + path + "'"; }; // (paths with blanks; a quote in a path is refused below)
@@ -1582,8 +1584,11 @@ static int prepare_one(vr_context *c) {
     c->traceMode = !c->absorb ? ((flatScene && c->geo.geo == 0 && c->kernelParticle <= (int)P_EXT) ? 3 : 0)
                               : (flatScene ? 1 : 2);
     c->looseMode = c->traceMode;
-    if (c->reliefScene) // flat with relief: the flat-scene kernels on the tight bins, the structured-scene ones on the loose
+    if (c->reliefScene) { // flat with relief: the flat-scene kernels on the tight bins, the structured-scene ones on the loose
       c->traceMode = c->absorb ? 5 : 6;
+      if (!c->absorb && !std::getenv("VR_NO_SPILL"))
+        c->looseMode = 7; // ... which also resume the rays the tight general kernel spills (TraceParams::spillRec)
+    }
     if (const char *e = std::getenv("VR_GENERAL_FLAT"))
       if (!c->absorb && c->geo.geo == 0 && c->kernelParticle <= (int)P_EXT)
         c->traceMode = std::atoi(e) ? 3 : 0;
@@ -1623,6 +1628,8 @@ static int prepare_one(vr_context *c) {
     if (c->reliefScene) { // (the loose bins hold about a tenth of the rays)
       int lb = std::max(1, trace_blocks_per_cu(D, c->geo.geo, c->kernelParticle, c->looseMode, 0));
       lb = std::min(lb, std::max(1, (int)std::lround(std::sqrt((double)cap / 1e6))));
+      if (const char *e = std::getenv("VR_LOOSE_BLOCKS"))
+        lb = std::max(1, std::atoi(e));
       c->looseGrid = (unsigned)c->numCUs * (unsigned)lb;
     }
   }
@@ -1717,6 +1724,14 @@ static int prepare_one(vr_context *c) {
   p.workCounter = c->dWorkQ.p;
   p.numQueues = VR_QUEUES;
   p.recExtra = c->recExtra ? c->dRecExtra.p : nullptr;
+  p.spillRec = nullptr;
+  p.spillCount = nullptr;
+  if (c->reliefScene && c->looseMode == 7) {
+    VR_HIP(c, c->dSpillRec.ensure_grow((size_t)c->batchCap * 16));
+    VR_HIP(c, c->dSpillCount.ensure(1));
+    p.spillRec = c->dSpillRec.p;
+    p.spillCount = c->dSpillCount.p;
+  }
   p.rngScratch = c->dScratch.p;
   p.slotRec = c->dSlotRec.p;
   p.binCount = c->dBinCount.p;
@@ -1997,6 +2012,8 @@ static int run_batch(vr_context *c, const std::vector<LaunchDesc> &group, uint64
   for (const LaunchDesc &L : group) {
     const TraceParams p = &L == &group[0] ? pg : batch_params(c, L, first, count);
     VR_HIP(c, hipMemsetAsync(p.workCounter, 0, VR_QUEUES * VR_QUEUE_STRIDE * 8, c->stream));
+    if (p.spillCount)
+      VR_HIP(c, hipMemsetAsync(p.spillCount, 0, 4, c->stream));
     hipEvent_t k0 = event_at(c->evK, 2 * traceNo, c, rc), k1 = event_at(c->evK, 2 * traceNo + 1, c, rc);
     if (rc != VR_OK)
       return rc;
@@ -2307,6 +2324,8 @@ int vr_apply_prepare(vr_context *c) {
     lp.rngScratch = c->dScratch.p;
     lp.workCounter = c->dWorkQ.p;
     lp.recExtra = lp.recExtra ? c->dRecExtra.p : nullptr;
+    lp.spillRec = lp.spillRec ? c->dSpillRec.p : nullptr;
+    lp.spillCount = lp.spillCount ? c->dSpillCount.p : nullptr;
     lp.counters = c->dCounters.p + 80 * q;
     lp.fluxAcc = c->dFluxAcc.p + (size_t)c->launches[q].dataBase * lp.planeStride;
   }

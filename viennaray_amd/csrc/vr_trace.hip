@@ -518,6 +518,7 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 #ifndef VR_RELIEF_WAVES
 #define VR_RELIEF_WAVES 8  // waves per SIMD of the absorbing relief kernel (MODE 5)
 #endif
+// MODE 7: MODE 0 that also resumes the rays of MODE 6's spill queue (TraceParams::spillRec) behind its bins
 constexpr int vr_mode_waves(int m) {
   return m == 5 ? VR_RELIEF_WAVES : m == 1 ? 8 : (m == 2 ? 7 : ((m == 3 || m == 6) ? VR_FLAT_WAVES : (m == 4 ? VR_SMALL_WAVES : VR_GENERAL_WAVES)));
 }
@@ -527,7 +528,8 @@ __attribute__((amdgpu_waves_per_eu(vr_mode_waves(MODE_), vr_mode_waves(MODE_))))
 trace_kernel(const TraceParams p) {
   constexpr bool SMALL = MODE_ == 4;
   constexpr bool RELIEF = MODE_ == 5 || MODE_ == 6;
-  constexpr int MODE = SMALL ? 0 : (MODE_ == 5 ? 1 : (MODE_ == 6 ? 3 : MODE_));
+  constexpr bool RESUME = MODE_ == 7;
+  constexpr int MODE = (SMALL || RESUME) ? 0 : (MODE_ == 5 ? 1 : (MODE_ == 6 ? 3 : MODE_));
   constexpr bool FRAME_LDS = MODE == 1; // (the wall / scene-box frame from LDS: hit_walls_lds, vr_device.hpp)
   constexpr bool FOLLOW = MODE == 3;    // (follow-up segments inside the round of a packet query: end of the round)
   constexpr bool ABSORB = MODE == 1 || MODE == 2;
@@ -667,7 +669,10 @@ trace_kernel(const TraceParams p) {
   typedef const unsigned __attribute__((address_space(4))) *ConstU32;
   ConstU32 binCount = (ConstU32)p.binCount;
   const unsigned ovCount = binCount[p.numBins] < p.ovCap ? binCount[p.numBins] : p.ovCap;
-  const unsigned totalBins = p.numBins + (ovCount + p.binCap - 1) / p.binCap;
+  const unsigned ovChunks = (ovCount + p.binCap - 1) / p.binCap;
+  // (MODE 7: the spill queue's records, in chunks of a bin's capacity, are the virtual bins behind the overflow chunks)
+  const unsigned spillN = (RESUME && p.spillRec) ? ((ConstU32)p.spillCount)[0] : 0u;
+  const unsigned totalBins = p.numBins + ovChunks + (RESUME ? (spillN + p.binCap - 1) / p.binCap : 0u);
   unsigned curBin = 0, spanStart = 0, spanEnd = 0, curOff = 0, curCnt = 0, curBase = 0;
   unsigned spanCounts = 0; // lane i: ray count of bin spanStart + i
   // (only the general flat-scene kernel has the queues compiled in — it is the one they pay for, vr_api.cpp — the others
@@ -762,10 +767,14 @@ trace_kernel(const TraceParams p) {
             const unsigned c = __shfl(spanCounts, (int)(curBin - spanStart), 64);
             curCnt = c < p.binCap ? c : p.binCap;
             curBase = curBin * p.binCap;
-          } else {
+          } else if (!RESUME || curBin < p.numBins + ovChunks) {
             const unsigned k = (curBin - p.numBins) * p.binCap;
             curCnt = ovCount - k < p.binCap ? ovCount - k : p.binCap;
             curBase = p.numBins * p.binCap + k;
+          } else { // a chunk of the spill queue: bit 31 marks its record numbers
+            const unsigned k = (curBin - p.numBins - ovChunks) * p.binCap;
+            curCnt = spillN - k < p.binCap ? spillN - k : p.binCap;
+            curBase = 0x80000000u | k;
           }
           curCnt = __builtin_amdgcn_readfirstlane(curCnt);
           continue;
@@ -777,7 +786,25 @@ trace_kernel(const TraceParams p) {
         curOff += take;
         assigned += take;
       }
-      if (slot != 0xFFFFFFFFu) {
+      bool resumed = false;
+      if (RESUME && slot != 0xFFFFFFFFu && (slot >> 31)) {
+        // a ray of the spill queue: its whole state as the relief kernel left it
+        const float4 *__restrict__ sr = reinterpret_cast<const float4 *>(p.spillRec) + 4 * (size_t)(slot & 0x7FFFFFFFu);
+        const float4 r0 = sr[0], r1 = sr[1], r2 = sr[2], r3 = sr[3];
+        org = mk(r0.x, r0.y, r0.z);
+        rayWeight = r0.w;
+        rayDirection = mk(r1.x, r1.y, r1.z);
+        dir = project_dir<D>(rayDirection);
+        rng_resume(rng, __float_as_uint(r1.w), __float_as_uint(r2.x),
+                   ((u64)__float_as_uint(r3.y) << 32) | __float_as_uint(r3.x), ((u64)__float_as_uint(r3.w) << 32) | __float_as_uint(r3.z));
+        numReflections = __float_as_uint(r2.y);
+        boundaryHits = __float_as_uint(r2.z) & 0x7FFFFFFFu;
+        hitFromBack = (__float_as_uint(r2.z) >> 31) != 0u;
+        active = true;
+        start = true;
+        resumed = true;
+      }
+      if (slot != 0xFFFFFFFFu && !resumed) {
         DIAG(8);
         const unsigned j = slot;
         const float4 a = rayAB[2 * (size_t)j]; // (32-byte records in both forms, vr_types.hpp)
@@ -1348,6 +1375,31 @@ trace_kernel(const TraceParams p) {
         }
       }
     }
+    if constexpr (FOLLOW && RELIEF) {
+      // ---- spill: a ray that would go on into the next round leaves as a full-state record (TraceParams::spillRec);
+      // the launch over the loose bins resumes it.  This kernel's waves then hold fresh, sorted rays only.
+      if (p.spillRec && !(p.debugFlags & 8192u)) { // (flag 8192: no spilling, for comparison)
+        const bool sp = active && start;
+        const unsigned long long sm = ballot64(sp);
+        if (sm) {
+          unsigned base = 0;
+          if (lane == (unsigned)(__ffsll((long long)sm) - 1))
+            base = atomicAdd(p.spillCount, (unsigned)__popcll(sm));
+          base = (unsigned)__shfl((int)base, __ffsll((long long)sm) - 1, 64);
+          if (sp) {
+            float4 *sr = reinterpret_cast<float4 *>(p.spillRec) + 4 * (size_t)(base + (unsigned)__popcll(sm & ((1ull << lane) - 1ull)));
+            sr[0] = make_float4(org.x, org.y, org.z, rayWeight);
+            sr[1] = make_float4(rayDirection.x, rayDirection.y, rayDirection.z, __uint_as_float(rng.seed)); // (the engine's seed: tea3(idx, seed))
+            sr[2] = make_float4(__uint_as_float(rng.k), __uint_as_float(numReflections),
+                                __uint_as_float(boundaryHits | (hitFromBack ? 0x80000000u : 0u)), 0.f);
+            sr[3] = make_float4(__uint_as_float((unsigned)(rng.lo & 0xFFFFFFFFull)), __uint_as_float((unsigned)(rng.lo >> 32)),
+                                __uint_as_float((unsigned)(rng.hi & 0xFFFFFFFFull)), __uint_as_float((unsigned)(rng.hi >> 32)));
+            active = false;
+            start = false;
+          }
+        }
+      }
+    }
     if constexpr (!ABSORB && !FOLLOW) {
       // ---- segments that rise clear (the general kernels without the packet query's candidate list).  A ray that goes
       // on after this round's event — reflected off the TOP surface of a structure: a fifth of all segments of a trench
@@ -1516,6 +1568,8 @@ static hipError_t launch_trace_t(const TraceParams &p, int mode, unsigned grid, 
     hipLaunchKernelGGL((trace_kernel<D, GEO, 0, 5>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else if (mode == 6 && GEO == 0 && PARTICLE <= P_EXT)
     hipLaunchKernelGGL((trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 6>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
+  else if (mode == 7 && GEO == 0 && PARTICLE <= P_EXT)
+    hipLaunchKernelGGL((trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 7>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   else
     hipLaunchKernelGGL((trace_kernel<D, GEO, PARTICLE, 0>), dim3(grid), dim3(VR_BLOCK), 0, s, p);
   return hipGetLastError();
@@ -1562,6 +1616,8 @@ template <int D, int GEO, int PARTICLE> static int occ_t(int mode, unsigned smal
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, 0, 5>, VR_BLOCK, 0);
   else if (mode == 6 && GEO == 0 && PARTICLE <= P_EXT)
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 6>, VR_BLOCK, 0);
+  else if (mode == 7 && GEO == 0 && PARTICLE <= P_EXT)
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, 0, ((PARTICLE > P_EXT) ? 0 : PARTICLE), 7>, VR_BLOCK, 0);
   else
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, trace_kernel<D, GEO, PARTICLE, 0>, VR_BLOCK, 0);
   return e == hipSuccess ? nb : 2;

@@ -161,6 +161,14 @@ struct TraceParams {
   uint32_t looseNumBins;
   int32_t looseT1, looseT2, looseTiles;
   int32_t reliefLookups;           // coarse look-ups of the generator's hit prediction (1 or 2)
+  // Spill queue of the general relief kernel (MODE 6): a ray that would go on into the NEXT round — its follow-up segment
+  // was not finished inside the round of its packet query — leaves the kernel as a 64-byte full-state record
+  //   {org.xyz, weight} {rayDirection.xyz, bits(idx - batchFirst)} {bits(k), bits(reflections), bits(boundaryHits | back << 31), -}
+  //   {s[k] lo, hi, s[k+156] lo, hi}
+  // and the launch over the loose bins (MODE 7 = MODE 0 + these records) traces it to its end: the tight kernel's waves
+  // then hold fresh, sorted primary rays only, whose packet queries stay small.
+  float *spillRec;                 // [batchCount] x 16 floats, or nullptr
+  uint32_t *spillCount;            // [1] records written (wave-aggregated cursor)
 };
 
 // Relief field over the source plane (vr_setup.hip: relief_field_kernel): per fine tile the [lo, hi] range — along the
