@@ -554,8 +554,8 @@ def main():
                          dict(name="C4", rays=100_000_000, sample=1_000_000, counters_key="C4"),
                          dict(name="C5p", rays=100_000_000, sample=1_000_000, counters_key="C5p"),
                          dict(name="C5r", rays=100_000_000, sample=1_000_000),
-                         dict(name="C2_rippled", rays=args.rays, sample=1_000_000, sticking=1.0),
-                         dict(name="C2_rippled", rays=args.rays, sample=1_000_000, sticking=0.1))
+                         dict(name="C2_rippled", rays=args.rays, sample=1_000_000, sticking=1.0, counters_key="C2_rippled_s1.0"),
+                         dict(name="C2_rippled", rays=args.rays, sample=1_000_000, sticking=0.1, counters_key="C2_rippled_s0.1"))
                 for cs in cases:
                     label = cs.pop("label", None)
                     if args.no_parity:

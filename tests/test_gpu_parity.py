@@ -800,6 +800,44 @@ def test_relief_packets_2d_and_triangles():
     assert t.traceMode() == 5
 
 
+def test_relief_packets_with_a_particle_list():
+    """Several particles in ONE apply on a scene with relief: an absorbing one (MODE 5 + MODE 2 over the loose bins), two
+    reflecting ones that share a generator pass (MODE 6 + MODE 7 each, one spill queue used in turn), a two-label registry
+    particle and a coned-cosine one (the full extended kernel has no relief variant: the general kernel, bins of its own)
+    — every counter and data label against one oracle run per particle."""
+    pts, nrm, gd = _relief_surface("ripple", n=120)
+    bcs = [BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY, BC.REFLECTIVE_BOUNDARY]
+    plist = [(vr.DiffuseParticle(1.0, "a"), po.DIFFUSE, 1.0, 1.0, 0.0),
+             (vr.DiffuseParticle(0.2, "b"), po.DIFFUSE, 0.2, 1.0, 0.0),
+             (vr.SpecularParticle(0.3, 1.0, "c"), po.SPECULAR, 0.3, 1.0, 0.0),
+             (vr.DiffuseCosineParticle(0.4, "d", "e"), po.DIFFUSE_COSINE, 0.4, 1.0, 0.0),
+             (vr.ConedCosineParticle(0.5, 1.0, 0.6, "f"), po.CONED_COSINE, 0.5, 1.0, 0.6)]
+    t = vr.TraceDisk(3)
+    t.setGeometry(pts, nrm, gd)
+    t.setBoundaryConditions(bcs)
+    t.setNumberOfRaysPerPoint(25)
+    t.setRngSeed(606)
+    t.setParticleTypes([q[0] for q in plist])
+    t.apply()
+    ld = t.getLocalData()
+    plane = 0
+    for q, (_, okind, s, power, cone) in enumerate(plist):
+        o = po.Oracle()
+        o.set_disks(pts, nrm, gd, 3)
+        o.set_boundary_conditions([int(b) for b in bcs])
+        o.set_particle_ex(okind, s, power, cone, -1.0)
+        o.set_num_rays_per_point(25)
+        o.set_rng_seed(606)
+        o.set_lazy_rng(True)
+        o.apply(po.max_threads())
+        pi, oi = t.getParticleTraceInfo(q), o.info()
+        assert {k: int(getattr(pi, k)) for k in INFO_KEYS} == {k: oi[k] for k in INFO_KEYS}, (q, okind)
+        for l in range(o.num_data()):
+            assert l2_rel(ld.getVectorData(plane), o.flux_data(l)) <= 5e-6, (q, okind, l)
+            plane += 1
+    assert plane == t.numData()
+
+
 def test_relief_is_for_thin_scenes_only():
     """A trench is not "flat with relief": its scene box is sixty cells deep — the general kernels as before."""
     gd, p, n = trench3d()

@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", tag)
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "publish_counters.py"), src, tag,
                        os.path.join(src, "issue_ceiling.json")])

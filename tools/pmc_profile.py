@@ -123,37 +123,63 @@ def main():
     except Exception as e:  # noqa: BLE001
         print("no case line:", e)
 
+    # A scene with relief runs TWO trace kernels per batch (the flat-scene kernel over the tight bins, the structured-scene
+    # kernel over the loose ones): dispatches are grouped by their full kernel name, reduced to a per-launch mean each, and
+    # the trace phase is the SUM over the instantiations (their times add up to the trace_kernel_ms the library reports).
+    def short(name):
+        return name.split("(")[0].replace("void ", "")
+
     out = {kk: {} for kk in KERNELS}
+    parts = {kk: {} for kk in KERNELS}   # kind -> full kernel name -> {avg_ms, counters}
     lines = []
     for f in glob.glob(os.path.join(work, "stats", "**", "*kernel_stats.csv"), recursive=True):
         lines.append("== rocprofv3 --kernel-trace --stats: " + " ".join(prog))
         lines.append(open(f).read())
     for f in glob.glob(os.path.join(work, "stats", "**", "*kernel_trace.csv"), recursive=True):
-        per = {kk: {} for kk in KERNELS}
+        per = {kk: defaultdict(dict) for kk in KERNELS}
         for r in csv.DictReader(open(f)):
             for kk in KERNELS:
                 if kk in r.get("Kernel_Name", ""):
-                    per[kk][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-                    out[kk]["name"] = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                    per[kk][short(r["Kernel_Name"])][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         for kk in KERNELS:
-            m = main_mean(per[kk])
-            if m:
-                out[kk]["avg_ms"] = m * 1e-6
-                out[kk]["launches"] = len([v for v in per[kk].values() if v > 0.1 * max(per[kk].values())])
+            for nm, disp in per[kk].items():
+                m = main_mean(disp)
+                if m:
+                    parts[kk].setdefault(nm, {})["avg_ms"] = m * 1e-6
+                    parts[kk][nm]["launches"] = len([v for v in disp.values() if v > 0.1 * max(disp.values())])
     for f in sorted(glob.glob(os.path.join(work, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
-        per = {kk: defaultdict(lambda: defaultdict(float)) for kk in KERNELS}
+        per = {kk: defaultdict(lambda: defaultdict(lambda: defaultdict(float))) for kk in KERNELS}
         for r in csv.DictReader(open(f)):
             for kk in KERNELS:
                 if kk in r.get("Kernel_Name", ""):
-                    per[kk][r["Counter_Name"]][r["Dispatch_Id"]] += float(r.get("Counter_Value", 0))
+                    per[kk][short(r["Kernel_Name"])][r["Counter_Name"]][r["Dispatch_Id"]] += float(r.get("Counter_Value", 0))
         for kk in KERNELS:
-            for cname, disp in per[kk].items():
-                out[kk][cname] = main_mean(disp)
+            for nm, ctrs in per[kk].items():
+                for cname, disp in ctrs.items():
+                    parts[kk].setdefault(nm, {})[cname] = main_mean(disp)
+    for kk in KERNELS:
+        # (instantiations that only ran warm-up-sized launches — under 3 % of the phase's time — are left out)
+        tot = sum(v.get("avg_ms", 0.0) for v in parts[kk].values())
+        names = sorted((nm for nm, v in parts[kk].items() if v.get("avg_ms", 0.0) >= 0.03 * tot and tot > 0), key=lambda nm: -parts[kk][nm]["avg_ms"])
+        if not names:
+            continue
+        out[kk]["name"] = " + ".join(names)
+        out[kk]["launches"] = parts[kk][names[0]].get("launches")
+        keys = set().union(*(parts[kk][nm].keys() for nm in names)) - {"launches"}
+        for key in keys:
+            vals = [parts[kk][nm].get(key) for nm in names]
+            if all(v is not None for v in vals):
+                out[kk][key] = sum(vals)
+        if len(names) > 1:
+            out[kk]["parts"] = {nm: {"avg_ms": parts[kk][nm].get("avg_ms")} for nm in names}
     for kk in KERNELS:
         derive(out[kk], segments if kk == "trace_kernel" else None)
         lines.append(f"== per launch, {kk}")
         for c, v in sorted(out[kk].items()):
             lines.append("   %-30s %s" % (c, ("%.6g" % v) if isinstance(v, float) else v))
+        if len(parts[kk]) > 1:
+            for nm, v in parts[kk].items():
+                lines.append("   per instantiation: %-60s avg %.4f ms x %s launches" % (nm, v.get("avg_ms", 0.0), v.get("launches")))
     res = dict(case=case, cmd=" ".join(prog), rays=rays, segments=segments, trace_kernel=out["trace_kernel"],
                gen_kernel=out["gen_kernel"])
     json.dump(res, open(os.path.join(outdir, case + ".json"), "w"), indent=1)

@@ -3,7 +3,7 @@
 #   usage: bash tools/run_final.sh <tag>          then, at home:  python3 tools/collect_final.py <tag>
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out/$TAG
 mkdir -p $O
 bash tools/run_profiles.sh $TAG > $O/profiles.log 2>&1; echo "profiles rc=$?"

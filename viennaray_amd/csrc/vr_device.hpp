@@ -479,8 +479,14 @@ __device__ __forceinline__ void hit_walls_lds(const TraceParams &p, const float 
 // coordinate, three orders above the rounding of a position) makes that tile's range hold the primitive as well.
 // After VR_RELIEF_STEPS tiles (a grazing ray that the generator did not file apart) the rest of the stretch is kept whole.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_minmax6(float &a, float &b, float &c, float &d, float &e, float &f);
+// WIN (the packet query's call: reached by the whole wave): the tiles under the wave's rays are first STAGED IN LDS — the
+// window of tiles between all the rays' first and last tile, when it holds at most 64 (it does unless a grazing ray is
+// among them): one load per lane, side by side, then every step of the per-lane walks reads LDS instead of making a
+// dependent trip to the L1 / L2.  `win`: 128 dwords of this wave (the query's frontier lists, not in use yet).
+template <bool WIN = false>
 __device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, bool on, const V3 &o, const V3 &d, float t0, float t1,
-                                            float &tA, float &tB) {
+                                            float &tA, float &tB, volatile __attribute__((address_space(3))) unsigned *win = nullptr) {
   typedef float F2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(1))) F2 *GlobalF2;
   const GlobalF2 field = reinterpret_cast<GlobalF2>(((unsigned long long)__float_as_uint(wallS[VR_F_RF_PTR_HI]) << 32) |
@@ -496,6 +502,35 @@ __device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, boo
   int ix = (int)floorf((o1 + d1 * t0 - lo1) * invT), iy = ny > 1 ? (int)floorf((o2 + d2 * t0 - lo2) * invT) : 0;
   ix = ix < 0 ? 0 : (ix >= nx ? nx - 1 : ix);
   iy = iy < 0 ? 0 : (iy >= ny ? ny - 1 : iy);
+  bool useWin = false;
+  int wx0 = 0, wy0 = 0, winW = 1;
+  if (WIN) {
+    int jx = (int)floorf((o1 + d1 * t1 - lo1) * invT), jy = ny > 1 ? (int)floorf((o2 + d2 * t1 - lo2) * invT) : 0;
+    jx = jx < 0 ? 0 : (jx >= nx ? nx - 1 : jx);
+    jy = jy < 0 ? 0 : (jy >= ny ? ny - 1 : jy);
+    const bool in = on && t0 <= t1;
+    float a = in ? (float)min(ix, jx) : big, b = in ? (float)min(iy, jy) : big, c = big;
+    float e = in ? (float)max(ix, jx) : -big, f = in ? (float)max(iy, jy) : -big, g = -big;
+    wave_minmax6(a, b, c, e, f, g); // (tile indices < 2^24: exact as floats)
+    if (a <= e) {
+      wx0 = (int)a;
+      wy0 = (int)b;
+      winW = (int)e - wx0 + 1;
+      const int winH = (int)f - wy0 + 1;
+      useWin = winW * winH <= 64;
+      if (useWin) {
+        const int l = (int)(threadIdx.x & 63u);
+        if (l < winW * winH) {
+          const int ty = (int)(((float)l + 0.5f) * __builtin_amdgcn_rcpf((float)winW)); // l / winW (operands <= 64: exact)
+          const int tx = l - ty * winW;
+          const F2 v = field[(wy0 + ty) * nx + (wx0 + tx)];
+          win[2 * l] = __float_as_uint(v.x);
+          win[2 * l + 1] = __float_as_uint(v.y);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
   const int sx = d1 > 0.f ? 1 : -1, sy = d2 > 0.f ? 1 : -1;
   const float inv1 = d1 != 0.f ? 1.0f / d1 : 0.f, inv2 = d2 != 0.f ? 1.0f / d2 : 0.f;
   float tx = d1 != 0.f ? (lo1 + (float)(ix + (d1 > 0.f ? 1 : 0)) * T - o1) * inv1 : big;
@@ -507,7 +542,14 @@ __device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, boo
   for (int s = 0; ballot64(go); ++s) {
     if (go) {
       const float tn = fminf(fminf(tx, ty), t1);
-      const F2 f = field[iy * nx + ix];
+      F2 f;
+      if (WIN && useWin) { // (the walk stays between the ray's first and last tile: inside the window)
+        const int k = 2 * ((iy - wy0) * winW + (ix - wx0));
+        f.x = __uint_as_float(win[k]);
+        f.y = __uint_as_float(win[k + 1]);
+      } else {
+        f = field[iy * nx + ix];
+      }
       const float z0 = oz + dz * tc, z1 = oz + dz * tn;
       if (fmaxf(z0, z1) >= f.x && fminf(z0, z1) <= f.y) {
         float ta = tc, tb = tn;
@@ -1054,7 +1096,10 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   float tEnd = tOut;
   if (RELIEF && !(p.debugFlags & 512u)) { // (flag 512: the scene box's clip, for comparison)
     float tA, tB;
-    relief_clip(wallS, valid, o, d, tQ, tOut, tA, tB);
+    if (p.debugFlags & 16384u) // (flag 16384: the tiles from global memory, for comparison)
+      relief_clip<false>(wallS, valid, o, d, tQ, tOut, tA, tB);
+    else
+      relief_clip<true>(wallS, valid, o, d, tQ, tOut, tA, tB, lst);
     valid = valid && tA <= tB;
     if (!ballot64(valid))
       return true; // no ray's height meets the relief under it

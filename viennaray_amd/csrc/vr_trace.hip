@@ -951,7 +951,7 @@ trace_kernel(const TraceParams p) {
     // packet, or — sampled on one lane's target — when a good share of the wave's hits fall on
     // the same primitive (sorted rays on a coarse scene: one vector atomic with 64 lanes on ONE
     // address is serialised lane by lane in the L2 atomic unit).
-    bool aggregate = packetDone;
+    bool aggregate = packetDone || (p.debugFlags & 32768u) != 0u; // (flag 32768: always, a measurement)
     {
       const bool cand = fin && h.geom == 1;
       const unsigned long long cm = ballot64(cand);
