@@ -2148,8 +2148,8 @@ int vr_apply_finish(vr_context *c) {
     unsigned long long ph[16];
     VR_HIP(c, hipMemcpy(ph, c->dCounters.p + 64, sizeof(ph), hipMemcpyDeviceToHost));
     static const char *pn[16] = {"refill", "packets", "walk: search", "walk: leaf tests", "walls", "state machine + credit",
-                                 "packet-query credit", "tail", "  (of state machine) neighbour loop", "  (of state machine) reflection + roulette", "  (of state machine) from its start to the back-face test (vote, miss / wall branches, normal fetch)", "  (of state machine) boundary hit",
-                                 "  (of state machine) up to the aggregation vote", "  (of state machine) up to the end counters", "-", "-"};
+                                 "packet-query credit", "tail", "  (of state machine) neighbour loop", "  (of state machine) reflection + roulette; (absorbing kernels: of packets) packet query: record loads + box tests of the last level", "  (of state machine) from its start to the back-face test (vote, miss / wall branches, normal fetch)", "  (of state machine) boundary hit",
+                                 "  (of state machine) up to the aggregation vote", "  (of state machine) up to the end counters", "  (of packets) packet query: descent of the 64-ary tree", "  (of packets) packet query: exact tests of the candidates"};
     double tot = 0;
     for (int k = 0; k < 8; ++k)
       tot += (double)ph[k];

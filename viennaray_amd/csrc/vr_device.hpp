@@ -1125,6 +1125,18 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
       cd.rec[VR_PQ_BOX + 1] = mk_u4(__float_as_uint(qhx), __float_as_uint(qhy), __float_as_uint(qhz), 0u);
     }
   }
+#ifdef VR_DIAG
+  unsigned long long pqT0 = __builtin_amdgcn_s_memtime();
+#define VR_PQ_MARK(k)                                                                                                  \
+  do {                                                                                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                      \
+    if ((threadIdx.x & 63u) == 0u)                                                                                     \
+      phaseT[k] += now_ - pqT0;                                                                                        \
+    pqT0 = now_;                                                                                                       \
+  } while (0)
+#else
+#define VR_PQ_MARK(k)
+#endif
   // breadth-first search of the 64-ary tree: a frontier entry = {first child, child count | prims flag}
   const float4 *__restrict__ wide = reinterpret_cast<const float4 *>(p.wide);
   const float4 *__restrict__ prims = reinterpret_cast<const float4 *>(p.prims);
@@ -1194,6 +1206,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
       return false;
   }
   unsigned tests = 0;
+  VR_PQ_MARK(14); // (diag: the descent)
   for (unsigned j = 0; j < nF; ++j) {
     const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)fFirst, (int)j);
     const unsigned cnt = (unsigned)__builtin_amdgcn_readlane((int)fCnt, (int)j) & 0x7FFFFFFFu;
@@ -1222,6 +1235,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
       }
     }
     unsigned long long m = ballot64(cand);
+    VR_PQ_MARK(9); // (diag: the candidates' record loads + box tests)
     while (m) {
       const int k = __ffsll((long long)m) - 1;
       m &= m - 1ull;
@@ -1261,6 +1275,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
       if (++tests > 2u * p.pqMaxCand)
         return false; // (only reachable with <= 2 leaf nodes: the hits found so far are real, the walk goes on from them)
     }
+    VR_PQ_MARK(15); // (diag: the exact tests)
   }
   return true;
 }
