@@ -580,6 +580,7 @@ SCHEDULING_KNOBS = [
     {"VR_GENERAL_FLAT": "1"}, {"VR_GENERAL_FLAT": "0"},  # packet-query crediting on / off in the general kernel
     {"VR_DEBUG_FLAGS": "256"},                        # no follow-up segments inside a packet-query round
     {"VR_MORTON_ANISO": "1"}, {"VR_MORTON_ANISO": "1000000"},  # Morton grid of cubes / in the scene box's proportions
+    {"VR_PQ_MARGIN": "0"}, {"VR_PQ_MARGIN": "0.2"}, {"VR_PQ_MARGIN": "6"},  # packet query: no / short-lived / far-reaching frontier cache
 ]
 
 
@@ -714,6 +715,7 @@ RELIEF_KNOBS = [
     {"VR_BIN_CAP": "8", "VR_RAYS_PER_BIN": "16"},  # most rays overflow their (tight or loose) bin
     {"VR_NO_SPILL": "1"}, {"VR_DEBUG_FLAGS": "8192"},  # continuing rays stay in the tight general kernel (no spill queue)
     {"VR_LOOSE_BLOCKS": "1"},
+    {"VR_PQ_MARGIN": "0"}, {"VR_PQ_MARGIN": "5"},  # packet query without / with a far-reaching frontier cache
 ]
 
 

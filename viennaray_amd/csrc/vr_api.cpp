@@ -650,7 +650,7 @@ int vr_register_particle_model(vr_context *c, const char *name, const char *sour
         // the launch parameters and the LDS frame as THIS library lays them out
         << "static_assert(sizeof(vr::TraceParams) == " << sizeof(TraceParams) << " && offsetof(vr::TraceParams, globalVec) == "
         << offsetof(TraceParams, globalVec) << " && offsetof(vr::TraceParams, counters) == " << offsetof(TraceParams, counters)
-        << " && offsetof(vr::TraceParams, spillCount) == " << offsetof(TraceParams, spillCount) << " && vr::VR_WALL_TABLE == "
+        << " && offsetof(vr::TraceParams, pqMargin) == " << offsetof(TraceParams, pqMargin) << " && vr::VR_WALL_TABLE == "
         << VR_WALL_TABLE << ", \"vr::TraceParams / the launch frame differ from the loaded library's: these kernel sources are not its own\");\n";
     }
     auto quoted = [](const std::string &path) { return "'" + path + "'"; }; // (paths with blanks; a quote in a path is refused below)
@@ -1671,7 +1671,7 @@ static int prepare_one(vr_context *c) {
   p.widePrimBase = c->wideRoot[2];
   p.pqMaxFrontier = 12;
   if (const char *e = std::getenv("VR_PQ_FRONTIER"))
-    p.pqMaxFrontier = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
+    p.pqMaxFrontier = (uint32_t)std::min(24, std::max(1, std::atoi(e))); // (<= 24: the cached frontier shares the lists with its box)
   p.pqMaxCand = 24;
   if (const char *e = std::getenv("VR_PQ_CAND"))
     p.pqMaxCand = (uint32_t)std::min(24, std::max(1, std::atoi(e))); // (2 * pqMaxCand + 1 records fit VR_PQ_CANDS)
@@ -1731,6 +1731,14 @@ static int prepare_one(vr_context *c) {
     VR_HIP(c, c->dSpillCount.ensure(1));
     p.spillRec = c->dSpillRec.p;
     p.spillCount = c->dSpillCount.p;
+  }
+  {
+    // the packet query's search margin (frontier reuse over neighbouring rounds, flat-scene kernels): in units of the
+    // neighbourhood distance 2 r (disks) / 1.7 grid cells (triangles); pqMaxFrontier <= 24 entries fit the cached lists
+    float mg = 1.5f;
+    if (const char *e = std::getenv("VR_PQ_MARGIN"))
+      mg = std::max(0.f, (float)std::atof(e));
+    p.pqMargin = mg * (c->geo.geo == 0 ? 2.f * c->geo.diskRadius : 1.7f * c->geo.gridDelta);
   }
   p.rngScratch = c->dScratch.p;
   p.slotRec = c->dSlotRec.p;

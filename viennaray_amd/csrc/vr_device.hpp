@@ -479,14 +479,8 @@ __device__ __forceinline__ void hit_walls_lds(const TraceParams &p, const float 
 // coordinate, three orders above the rounding of a position) makes that tile's range hold the primitive as well.
 // After VR_RELIEF_STEPS tiles (a grazing ray that the generator did not file apart) the rest of the stretch is kept whole.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void wave_minmax6(float &a, float &b, float &c, float &d, float &e, float &f);
-// WIN (the packet query's call: reached by the whole wave): the tiles under the wave's rays are first STAGED IN LDS — the
-// window of tiles between all the rays' first and last tile, when it holds at most 64 (it does unless a grazing ray is
-// among them): one load per lane, side by side, then every step of the per-lane walks reads LDS instead of making a
-// dependent trip to the L1 / L2.  `win`: 128 dwords of this wave (the query's frontier lists, not in use yet).
-template <bool WIN = false>
 __device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, bool on, const V3 &o, const V3 &d, float t0, float t1,
-                                            float &tA, float &tB, volatile __attribute__((address_space(3))) unsigned *win = nullptr) {
+                                            float &tA, float &tB) {
   typedef float F2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(1))) F2 *GlobalF2;
   const GlobalF2 field = reinterpret_cast<GlobalF2>(((unsigned long long)__float_as_uint(wallS[VR_F_RF_PTR_HI]) << 32) |
@@ -502,35 +496,6 @@ __device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, boo
   int ix = (int)floorf((o1 + d1 * t0 - lo1) * invT), iy = ny > 1 ? (int)floorf((o2 + d2 * t0 - lo2) * invT) : 0;
   ix = ix < 0 ? 0 : (ix >= nx ? nx - 1 : ix);
   iy = iy < 0 ? 0 : (iy >= ny ? ny - 1 : iy);
-  bool useWin = false;
-  int wx0 = 0, wy0 = 0, winW = 1;
-  if (WIN) {
-    int jx = (int)floorf((o1 + d1 * t1 - lo1) * invT), jy = ny > 1 ? (int)floorf((o2 + d2 * t1 - lo2) * invT) : 0;
-    jx = jx < 0 ? 0 : (jx >= nx ? nx - 1 : jx);
-    jy = jy < 0 ? 0 : (jy >= ny ? ny - 1 : jy);
-    const bool in = on && t0 <= t1;
-    float a = in ? (float)min(ix, jx) : big, b = in ? (float)min(iy, jy) : big, c = big;
-    float e = in ? (float)max(ix, jx) : -big, f = in ? (float)max(iy, jy) : -big, g = -big;
-    wave_minmax6(a, b, c, e, f, g); // (tile indices < 2^24: exact as floats)
-    if (a <= e) {
-      wx0 = (int)a;
-      wy0 = (int)b;
-      winW = (int)e - wx0 + 1;
-      const int winH = (int)f - wy0 + 1;
-      useWin = winW * winH <= 64;
-      if (useWin) {
-        const int l = (int)(threadIdx.x & 63u);
-        if (l < winW * winH) {
-          const int ty = (int)(((float)l + 0.5f) * __builtin_amdgcn_rcpf((float)winW)); // l / winW (operands <= 64: exact)
-          const int tx = l - ty * winW;
-          const F2 v = field[(wy0 + ty) * nx + (wx0 + tx)];
-          win[2 * l] = __float_as_uint(v.x);
-          win[2 * l + 1] = __float_as_uint(v.y);
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
   const int sx = d1 > 0.f ? 1 : -1, sy = d2 > 0.f ? 1 : -1;
   const float inv1 = d1 != 0.f ? 1.0f / d1 : 0.f, inv2 = d2 != 0.f ? 1.0f / d2 : 0.f;
   float tx = d1 != 0.f ? (lo1 + (float)(ix + (d1 > 0.f ? 1 : 0)) * T - o1) * inv1 : big;
@@ -542,14 +507,9 @@ __device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, boo
   for (int s = 0; ballot64(go); ++s) {
     if (go) {
       const float tn = fminf(fminf(tx, ty), t1);
-      F2 f;
-      if (WIN && useWin) { // (the walk stays between the ray's first and last tile: inside the window)
-        const int k = 2 * ((iy - wy0) * winW + (ix - wx0));
-        f.x = __uint_as_float(win[k]);
-        f.y = __uint_as_float(win[k + 1]);
-      } else {
-        f = field[iy * nx + ix];
-      }
+      // (staging the wave's window of tiles in LDS first — one load per lane, then LDS reads in the walk — was built and
+      //  measured in round 4: +- 0, the tiles are L1 hits; the lists it used now hold the frontier cache)
+      const F2 f = field[iy * nx + ix];
       const float z0 = oz + dz * tc, z1 = oz + dz * tn;
       if (fmaxf(z0, z1) >= f.x && fminf(z0, z1) <= f.y) {
         float ta = tc, tb = tn;
@@ -1071,10 +1031,18 @@ constexpr unsigned VR_PQ_RECORDS = 2 * 52;
 // lst: 128 dwords of LDS private to this wave
 // FRAME_LDS: the scene box and the padding come from the LDS frame `wallS` (see hit_walls_lds)
 // RELIEF: the rays are clipped to the local relief (relief_clip) instead of to the scene box
-template <int GEO, bool CREDIT, bool FRAME_LDS = false, bool KEEPQ = false, bool RELIEF = false>
+// CACHE (the flat-scene kernels): consecutive rounds of a wave are neighbours in space — its bins follow a boustrophedon
+// path — and the descent of the 64-ary tree is latency: three dependent node loads before the first primitive record
+// (27 % of the flat kernel's wave time, -DVR_DIAG sub-phase timers).  A query therefore searches with its box ENLARGED by
+// pqMargin and leaves its last-level frontier (the leaf nodes meeting the enlarged box S: complete for every box inside
+// S, at most 12) with S in the wave's LDS lists (lst[0..], lst[64..]: the entries; lst[32..37]: S; lst[38]: their number;
+// lst[39]: valid; cboxes: the leaf nodes' own boxes); a later round whose box lies inside S filters the kept nodes by ITS
+// box — from LDS, no node load — and goes straight to the primitive records of those that meet it: the very nodes an
+// exact descent would have found.  The candidates are filtered with the round's own box as before: bit-identical.
+template <int GEO, bool CREDIT, bool FRAME_LDS = false, bool KEEPQ = false, bool RELIEF = false, bool CACHE = false>
 __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
                                               HitRec &h, volatile VR_LDS unsigned *lst, PqCands &cd,
-                                              const float *__restrict__ wallS VR_DIAG_ARGS) {
+                                              const float *__restrict__ wallS, volatile VR_LDS float *cboxes VR_DIAG_ARGS) {
   const unsigned lane = threadIdx.x & 63u;
   // the ray's stretch inside the scene box
   const V3 inv = safe_inverse(d);
@@ -1096,10 +1064,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   float tEnd = tOut;
   if (RELIEF && !(p.debugFlags & 512u)) { // (flag 512: the scene box's clip, for comparison)
     float tA, tB;
-    if (p.debugFlags & 16384u) // (flag 16384: the tiles from global memory, for comparison)
-      relief_clip<false>(wallS, valid, o, d, tQ, tOut, tA, tB);
-    else
-      relief_clip<true>(wallS, valid, o, d, tQ, tOut, tA, tB, lst);
+    relief_clip(wallS, valid, o, d, tQ, tOut, tA, tB);
     valid = valid && tA <= tB;
     if (!ballot64(valid))
       return true; // no ray's height meets the relief under it
@@ -1143,6 +1108,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   unsigned fFirst = p.wideTopFirst, fCnt = p.wideTopCount;
   unsigned nF = 1;
   const unsigned long long ltMask = (1ull << lane) - 1ull;
+  if constexpr (!CACHE) {
   while (!((unsigned)__builtin_amdgcn_readlane((int)fCnt, 0) & VR_WIDE_PRIMS)) {
     unsigned nNext = 0;
     for (unsigned j = 0; j < nF; ++j) {
@@ -1172,6 +1138,96 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
     fFirst = lst[lane];
     fCnt = lst[64u + lane];
     nF = nNext;
+  }
+  } else { // CACHE: the same search with an enlarged box, its frontier kept for the neighbouring rounds
+    constexpr unsigned KEEP = 12; // cached leaf nodes (entries lst[0 ..], lst[64 ..]; their boxes: cboxes, 6 floats each)
+    const bool caching = p.pqMargin > 0.f && !(fCnt & VR_WIDE_PRIMS);
+    bool haveList = false;
+    if (caching && lst[39] != 0u) {
+      // is the frontier the last search left complete for this round's box?
+      const bool inside = qlx >= __uint_as_float(lst[32]) && qly >= __uint_as_float(lst[33]) && qlz >= __uint_as_float(lst[34]) &&
+                          qhx <= __uint_as_float(lst[35]) && qhy <= __uint_as_float(lst[36]) && qhz <= __uint_as_float(lst[37]);
+      haveList = __builtin_amdgcn_readfirstlane((int)inside) != 0; // (wave-uniform: every operand is)
+    }
+    if (!haveList) {
+      // the search box: the round's own, or — caching — enlarged, so that its frontier serves the neighbouring rounds too
+      const float mg = caching ? p.pqMargin : 0.f;
+      const float elx = qlx - mg, ely = qly - mg, elz = qlz - mg, ehx = qhx + mg, ehy = qhy + mg, ehz = qhz + mg;
+      if (caching && lane == 0u)
+        lst[39] = 0u; // (the lists are about to be overwritten; a search that gives up leaves no cache)
+      while (!((unsigned)__builtin_amdgcn_readlane((int)fCnt, 0) & VR_WIDE_PRIMS)) {
+        unsigned nNext = 0;
+        for (unsigned j = 0; j < nF; ++j) {
+          const unsigned first = (unsigned)__builtin_amdgcn_readlane((int)fFirst, (int)j);
+          const unsigned cnt = (unsigned)__builtin_amdgcn_readlane((int)fCnt, (int)j);
+          bool hit = false;
+          unsigned cf = 0, cc = 0;
+          float4 a = make_float4(0, 0, 0, 0), b = a;
+          if (lane < cnt) {
+            DIAG(3);
+            a = wide[2 * (size_t)(first + lane)];
+            b = wide[2 * (size_t)(first + lane) + 1];
+            hit = a.x <= ehx && b.x >= elx && a.y <= ehy && b.y >= ely && a.z <= ehz && b.z >= elz;
+            cf = __float_as_uint(a.w);
+            cc = __float_as_uint(b.w);
+          }
+          const unsigned long long m = ballot64(hit);
+          const unsigned pos = nNext + (unsigned)__popcll(m & ltMask);
+          if (hit && pos < 64u) {
+            lst[pos] = cf;
+            lst[64u + pos] = cc;
+            if (caching && pos < KEEP) { // (kept only where this turns out to be the last level)
+              cboxes[6u * pos] = a.x, cboxes[6u * pos + 1u] = a.y, cboxes[6u * pos + 2u] = a.z;
+              cboxes[6u * pos + 3u] = b.x, cboxes[6u * pos + 4u] = b.y, cboxes[6u * pos + 5u] = b.z;
+            }
+          }
+          nNext += (unsigned)__popcll(m);
+        }
+        if (nNext > p.pqMaxFrontier)
+          return false; // (nothing touched yet)
+        if (nNext == 0u && !caching)
+          return true;
+        fFirst = lst[lane];
+        fCnt = lst[64u + lane];
+        nF = nNext;
+        if (nNext == 0u)
+          break; // (nothing meets the enlarged box: an empty frontier, complete for it)
+      }
+      if (caching) {
+        if (nF <= KEEP) {
+          if (lane == 0u) {
+            lst[32] = __float_as_uint(elx), lst[33] = __float_as_uint(ely), lst[34] = __float_as_uint(elz);
+            lst[35] = __float_as_uint(ehx), lst[36] = __float_as_uint(ehy), lst[37] = __float_as_uint(ehz);
+            lst[38] = nF;
+            lst[39] = 1u;
+          }
+          haveList = true;
+        }
+      }
+    }
+    if (haveList) {
+      // the kept leaf nodes that meet THIS round's box (their boxes from LDS: no node load, no dependent trip)
+      const unsigned nC = (unsigned)__builtin_amdgcn_readfirstlane((int)lst[38]);
+      bool meet = false;
+      unsigned f0 = 0, c0 = 0;
+      if (lane < nC) {
+        const volatile VR_LDS float *bx = cboxes + 6u * lane;
+        meet = bx[0] <= qhx && bx[3] >= qlx && bx[1] <= qhy && bx[4] >= qly && bx[2] <= qhz && bx[5] >= qlz;
+        f0 = lst[lane];
+        c0 = lst[64u + lane];
+      }
+      const unsigned long long m = ballot64(meet);
+      nF = (unsigned)__popcll(m);
+      if (nF == 0u)
+        return true;
+      if (meet) {
+        const unsigned pos = (unsigned)__popcll(m & ltMask);
+        lst[16u + pos] = f0;
+        lst[80u + pos] = c0;
+      }
+      fFirst = lst[16u + lane];
+      fCnt = lst[80u + lane];
+    }
   }
   // last level: the frontier's children are primitives.  Lanes load the RECORDS of a node's
   // (<= 64) primitives, keep those whose bounds meet Q, and every kept record is broadcast from

@@ -509,6 +509,12 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 #ifndef VR_SMALL_WAVES
 #define VR_SMALL_WAVES 5   // ... of the LDS-resident kernel (MODE 4; 6: C5 20.15 -> 21.9 ms)
 #endif
+#ifndef VR_PQ_CACHE
+#define VR_PQ_CACHE 1      // flat-scene kernels: the packet query's frontier serves the neighbouring rounds (pq_hit_packet CACHE)
+#endif
+#ifndef VR_PQ_CACHE_RELIEF
+#define VR_PQ_CACHE_RELIEF 1 // ... in the relief kernels MODE 5 / 6 too
+#endif
 #ifndef VR_FLAT_WAVES
 #define VR_FLAT_WAVES 6    // ... of the general flat-scene kernel (MODE 3)
 #endif
@@ -558,6 +564,8 @@ trace_kernel(const TraceParams p) {
   // 7 waves per SIMD and at 6; removed.)
   __shared__ unsigned cntS[8 * VR_BLOCK];
   __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier lists
+  constexpr bool PQ_CACHE = (MODE == 1 || MODE == 3) && (!RELIEF || VR_PQ_CACHE_RELIEF) && VR_PQ_CACHE != 0; // (pq_hit_packet CACHE: flat-scene kernels)
+  __shared__ float pqBoxS[PQ_CACHE ? (VR_BLOCK / 64) * 72 : 1];                     // ... the kept leaf nodes' boxes, 12 x 6 per wave
   __shared__ uint4 candS[PQ_CREDIT ? (VR_BLOCK / 64) * VR_PQ_RECORDS : 1]; // ... and candidate records (pq_credit)
   // ... and, where the credits of a round carry different weights (the general kernels), one int64 sum per candidate
   // and data label (two labels here; further ones are summed over the wave in registers)
@@ -588,6 +596,10 @@ trace_kernel(const TraceParams p) {
 #pragma unroll
   for (int k = 0; k < 8; ++k)
     cntS[k * VR_BLOCK + tid] = 0u;
+  if constexpr (PQ_CACHE) {
+    if (tid < VR_BLOCK / 64)
+      pqS[tid * 128 + 39] = 0u; // (no cached frontier yet: pq_hit_packet CACHE)
+  }
   if (SMALL) {
     // stage the scene (the offsets are multiples of 16 bytes; vr_apply_prepare checked that it fits)
     const uint4 *gn = reinterpret_cast<const uint4 *>(p.pnodes);
@@ -887,7 +899,7 @@ trace_kernel(const TraceParams p) {
         if (active) {
           DIAG(12);
         }
-        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW, RELIEF>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + waveInBlock * 128u), cands, wallS VR_DIAG_PASS);
+        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW, RELIEF, PQ_CACHE>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + waveInBlock * 128u), cands, wallS, (volatile VR_LDS float *)(pqBoxS + (PQ_CACHE ? waveInBlock * 72u : 0u)) VR_DIAG_PASS);
         pqCredit = PQ_CREDIT && packetDone;
         pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
         pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;

@@ -169,6 +169,8 @@ struct TraceParams {
   // then hold fresh, sorted primary rays only, whose packet queries stay small.
   float *spillRec;                 // [batchCount] x 16 floats, or nullptr
   uint32_t *spillCount;            // [1] records written (wave-aggregated cursor)
+  float pqMargin;                  // flat-scene kernels: a packet query searches the 64-ary tree with its box enlarged by this
+                                   // much, and the frontier it finds serves the following rounds whose boxes lie inside (0: off)
 };
 
 // Relief field over the source plane (vr_setup.hip: relief_field_kernel): per fine tile the [lo, hi] range — along the
