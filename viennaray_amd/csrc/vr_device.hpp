@@ -1042,7 +1042,7 @@ constexpr unsigned VR_PQ_RECORDS = 2 * 52;
 template <int GEO, bool CREDIT, bool FRAME_LDS = false, bool KEEPQ = false, bool RELIEF = false, bool CACHE = false>
 __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, const V3 &o, const V3 &d, float tnear,
                                               HitRec &h, volatile VR_LDS unsigned *lst, PqCands &cd,
-                                              const float *__restrict__ wallS, volatile VR_LDS float *cboxes VR_DIAG_ARGS) {
+                                              const float *__restrict__ wallS, volatile VR_LDS float *cboxes, float tWall VR_DIAG_ARGS) {
   const unsigned lane = threadIdx.x & 63u;
   // the ray's stretch inside the scene box
   const V3 inv = safe_inverse(d);
@@ -1051,7 +1051,11 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
   const float tz0 = ((FRAME_LDS ? wallS[VR_F_SCENE_LO + 2] : p.sceneLo[2]) - o.z) * inv.z, tz1 = ((FRAME_LDS ? wallS[VR_F_SCENE_HI + 2] : p.sceneHi[2]) - o.z) * inv.z;
   const float tIn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tnear));
   const float tOut = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
-  bool valid = part && tIn <= tOut;
+  // tWall: the exact wall test's hit of this ray (or infinity).  A ray that meets a side wall BEFORE it can enter the scene
+  // box cannot meet the geometry first (a hit has t >= tIn up to a few ulp: the margin): it stays out of the query's box.
+  // Such rays were binned — folded by the boundary condition — with the rays on the far side of the domain, and one of them
+  // stretched its wave's box across the whole scene: every packet query of a flat plane that gave up was one of these.
+  bool valid = part && tIn <= tOut && !(tWall < tIn * 0.99999f);
   cd.count = 0;
   cd.local = 0ull;
   const float big = 3.0e38f;
@@ -1183,8 +1187,10 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
           }
           nNext += (unsigned)__popcll(m);
         }
-        if (nNext > p.pqMaxFrontier)
+        if (nNext > p.pqMaxFrontier) {
+          DIAG(14); // (diag: gave up on the frontier)
           return false; // (nothing touched yet)
+        }
         if (nNext == 0u && !caching)
           return true;
         fFirst = lst[lane];
@@ -1258,8 +1264,10 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
       }
       total += (unsigned)__popcll(ballot64(cand));
     }
-    if (total > p.pqMaxCand)
+    if (total > p.pqMaxCand) {
+      DIAG(15); // (diag: gave up on the candidate count)
       return false;
+    }
   }
   unsigned tests = 0;
   VR_PQ_MARK(14); // (diag: the descent)
@@ -1328,8 +1336,10 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
         const bool ok = hit_tri(o, d, tnear, v0, e1, e2, Ng, t);
         hit_update(h, part && ok, t, orig, qq);
       }
-      if (++tests > 2u * p.pqMaxCand)
+      if (++tests > 2u * p.pqMaxCand) {
+        DIAG(10); // (diag: gave up in the exact tests)
         return false; // (only reachable with <= 2 leaf nodes: the hits found so far are real, the walk goes on from them)
+      }
     }
     VR_PQ_MARK(15); // (diag: the exact tests)
   }

@@ -512,6 +512,9 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
 #ifndef VR_PQ_CACHE
 #define VR_PQ_CACHE 1      // flat-scene kernels: the packet query's frontier serves the neighbouring rounds (pq_hit_packet CACHE)
 #endif
+#ifndef VR_PQ_WALLS_FIRST
+#define VR_PQ_WALLS_FIRST 1 // flat-scene kernels: a ray that meets a side wall before the scene box stays out of the packet query's box
+#endif
 #ifndef VR_PQ_CACHE_RELIEF
 #define VR_PQ_CACHE_RELIEF 1 // ... in the relief kernels MODE 5 / 6 too
 #endif
@@ -899,7 +902,21 @@ trace_kernel(const TraceParams p) {
         if (active) {
           DIAG(12);
         }
-        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW, RELIEF, PQ_CACHE>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + waveInBlock * 128u), cands, wallS, (volatile VR_LDS float *)(pqBoxS + (PQ_CACHE ? waveInBlock * 72u : 0u)) VR_DIAG_PASS);
+        // (the walls first for the flat-scene kernels' queries: see pq_hit_packet, tWall.  The conservative pre-tests of
+        //  hit_walls let only the rays near a side wall through to the exact test)
+        float tWall = 3.402823466e+38f;
+        if constexpr ((MODE == 1 || MODE == 3) && VR_PQ_WALLS_FIRST) {
+          if (active && !(p.debugFlags & 65536u)) { // (flag 65536: off, for comparison)
+            HitRec hw;
+            hit_clear(hw);
+            if constexpr (FRAME_LDS)
+              hit_walls_lds(p, wallS, org, dir, tnear, hw);
+            else
+              hit_walls(p, wallS, org, dir, tnear, hw);
+            tWall = hw.geom == 0 ? hw.t : tWall;
+          }
+        }
+        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW, RELIEF, PQ_CACHE>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + waveInBlock * 128u), cands, wallS, (volatile VR_LDS float *)(pqBoxS + (PQ_CACHE ? waveInBlock * 72u : 0u)), tWall VR_DIAG_PASS);
         pqCredit = PQ_CREDIT && packetDone;
         pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
         pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;
