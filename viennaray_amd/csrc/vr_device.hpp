@@ -1004,6 +1004,9 @@ __device__ __forceinline__ float lane_bcast(float v, int srcLane) {
 // space inference leaves such accesses on GENERIC pointers, i.e. flat_load / flat_store (the slow path to LDS, waiting on
 // both memory counters) — the packet query's frontier lists were read and written that way until round 3.
 #define VR_LDS __attribute__((address_space(3)))
+#ifndef VR_PQ_KEEP
+#define VR_PQ_KEEP 12 // leaf nodes a packet query's frontier cache keeps per wave (<= 16: the compacted list starts at lst[16])
+#endif
 typedef unsigned U4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ U4 mk_u4(unsigned x, unsigned y, unsigned z, unsigned w) {
   U4 v;
@@ -1144,7 +1147,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
     nF = nNext;
   }
   } else { // CACHE: the same search with an enlarged box, its frontier kept for the neighbouring rounds
-    constexpr unsigned KEEP = 12; // cached leaf nodes (entries lst[0 ..], lst[64 ..]; their boxes: cboxes, 6 floats each)
+    constexpr unsigned KEEP = VR_PQ_KEEP; // cached leaf nodes (entries lst[0 ..], lst[64 ..]; their boxes: cboxes, 6 floats each)
     const bool caching = p.pqMargin > 0.f && !(fCnt & VR_WIDE_PRIMS);
     bool haveList = false;
     if (caching && lst[39] != 0u) {

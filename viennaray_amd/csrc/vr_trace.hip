@@ -568,7 +568,7 @@ trace_kernel(const TraceParams p) {
   __shared__ unsigned cntS[8 * VR_BLOCK];
   __shared__ unsigned pqS[(VR_BLOCK / 64) * 128]; // packet query: per-wave frontier lists
   constexpr bool PQ_CACHE = (MODE == 1 || MODE == 3) && (!RELIEF || VR_PQ_CACHE_RELIEF) && VR_PQ_CACHE != 0; // (pq_hit_packet CACHE: flat-scene kernels)
-  __shared__ float pqBoxS[PQ_CACHE ? (VR_BLOCK / 64) * 72 : 1];                     // ... the kept leaf nodes' boxes, 12 x 6 per wave
+  __shared__ float pqBoxS[PQ_CACHE ? (VR_BLOCK / 64) * 6 * VR_PQ_KEEP : 1];         // ... the kept leaf nodes' boxes, VR_PQ_KEEP x 6 per wave
   __shared__ uint4 candS[PQ_CREDIT ? (VR_BLOCK / 64) * VR_PQ_RECORDS : 1]; // ... and candidate records (pq_credit)
   // ... and, where the credits of a round carry different weights (the general kernels), one int64 sum per candidate
   // and data label (two labels here; further ones are summed over the wave in registers)
@@ -916,7 +916,7 @@ trace_kernel(const TraceParams p) {
             tWall = hw.geom == 0 ? hw.t : tWall;
           }
         }
-        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW, RELIEF, PQ_CACHE>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + waveInBlock * 128u), cands, wallS, (volatile VR_LDS float *)(pqBoxS + (PQ_CACHE ? waveInBlock * 72u : 0u)), tWall VR_DIAG_PASS);
+        packetDone = pq_hit_packet<GEO, PQ_CREDIT, FRAME_LDS, FOLLOW, RELIEF, PQ_CACHE>(p, active, org, dir, tnear, h, (volatile VR_LDS unsigned *)(pqS + waveInBlock * 128u), cands, wallS, (volatile VR_LDS float *)(pqBoxS + (PQ_CACHE ? waveInBlock * (6u * VR_PQ_KEEP) : 0u)), tWall VR_DIAG_PASS);
         pqCredit = PQ_CREDIT && packetDone;
         pqFails = packetDone ? 0u : (pqFails < 6u ? pqFails + 1u : 6u);
         pqSkip = packetDone ? 0u : (1u << pqFails) - 1u;
