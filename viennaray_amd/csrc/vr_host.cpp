@@ -468,6 +468,125 @@ struct Builder {
 };
 } // namespace
 
+namespace {
+// Binned-SAH top-down builder over the same (padded) primitive boxes: the permutation is refined in place, a leaf is a
+// contiguous run of it, nodes are emitted in pre-order like the LBVH's — the rest of the pipeline cannot tell the two
+// trees apart.  (VR_HOST_BUILD=2; tree quality experiment for the per-lane walks of the bounce-heavy workloads)
+struct SahBuilder {
+  const std::vector<float> &box; // 6 per primitive, ORIGINAL order
+  std::vector<uint32_t> &order;  // permutation being refined
+  std::vector<float> &nodes;
+  std::vector<uint32_t> right;
+  uint32_t leafMax = VR_LEAF_MAX, leaves = 0, maxDepth = 0;
+
+  static float area(const float *lo, const float *hi) {
+    const float dx = std::max(hi[0] - lo[0], 0.f), dy = std::max(hi[1] - lo[1], 0.f), dz = std::max(hi[2] - lo[2], 0.f);
+    return dx * dy + dy * dz + dz * dx;
+  }
+  uint32_t build(uint32_t first, uint32_t last, uint32_t depth) { // inclusive range of `order`
+    const uint32_t me = (uint32_t)(nodes.size() / 8);
+    nodes.resize(nodes.size() + 8);
+    right.push_back(0);
+    maxDepth = std::max(maxDepth, depth);
+    const uint32_t cnt = last - first + 1;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (uint32_t i = first; i <= last; ++i) {
+      const float *b = &box[6 * (size_t)order[i]];
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = std::min(lo[k], b[k]);
+        hi[k] = std::max(hi[k], b[3 + k]);
+        const float c = 0.5f * (b[k] + b[3 + k]);
+        clo[k] = std::min(clo[k], c);
+        chi[k] = std::max(chi[k], c);
+      }
+    }
+    if (cnt <= leafMax) {
+      const uint32_t link = VR_LEAF | (cnt << 27) | first;
+      float *nd = &nodes[8 * (size_t)me];
+      std::memcpy(nd, lo, 12);
+      std::memcpy(nd + 3, &link, 4);
+      std::memcpy(nd + 4, hi, 12);
+      ++leaves;
+      return me;
+    }
+    // best binned split over the three axes
+    constexpr int NB = 16;
+    int bestAxis = -1, bestBin = 0;
+    float bestCost = FLT_MAX;
+    for (int ax = 0; ax < 3; ++ax) {
+      const float ext = chi[ax] - clo[ax];
+      if (!(ext > 0.f))
+        continue;
+      const float scale = NB / ext;
+      uint32_t bc[NB] = {0};
+      float blo[NB][3], bhi[NB][3];
+      for (int b = 0; b < NB; ++b)
+        for (int k = 0; k < 3; ++k)
+          blo[b][k] = FLT_MAX, bhi[b][k] = -FLT_MAX;
+      for (uint32_t i = first; i <= last; ++i) {
+        const float *b = &box[6 * (size_t)order[i]];
+        int bi = (int)((0.5f * (b[ax] + b[3 + ax]) - clo[ax]) * scale);
+        bi = bi < 0 ? 0 : (bi >= NB ? NB - 1 : bi);
+        ++bc[bi];
+        for (int k = 0; k < 3; ++k) {
+          blo[bi][k] = std::min(blo[bi][k], b[k]);
+          bhi[bi][k] = std::max(bhi[bi][k], b[3 + k]);
+        }
+      }
+      float rA[NB];
+      uint32_t rN[NB];
+      {
+        float l[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, h[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        uint32_t c = 0;
+        for (int b = NB - 1; b > 0; --b) {
+          for (int k = 0; k < 3; ++k)
+            l[k] = std::min(l[k], blo[b][k]), h[k] = std::max(h[k], bhi[b][k]);
+          c += bc[b];
+          rA[b] = c ? area(l, h) : 0.f;
+          rN[b] = c;
+        }
+      }
+      float l[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, h[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+      uint32_t c = 0;
+      for (int b = 0; b < NB - 1; ++b) { // split between bin b and b + 1
+        for (int k = 0; k < 3; ++k)
+          l[k] = std::min(l[k], blo[b][k]), h[k] = std::max(h[k], bhi[b][k]);
+        c += bc[b];
+        if (c == 0 || rN[b + 1] == 0)
+          continue;
+        const float cost = area(l, h) * (float)c + rA[b + 1] * (float)rN[b + 1];
+        if (cost < bestCost)
+          bestCost = cost, bestAxis = ax, bestBin = b;
+      }
+    }
+    uint32_t mid; // first index of the right part
+    if (bestAxis < 0) {
+      mid = first + cnt / 2; // (all centres coincide)
+    } else {
+      const float scale = NB / (chi[bestAxis] - clo[bestAxis]);
+      auto it = std::partition(order.begin() + first, order.begin() + last + 1, [&](uint32_t o) {
+        const float *b = &box[6 * (size_t)o];
+        int bi = (int)((0.5f * (b[bestAxis] + b[3 + bestAxis]) - clo[bestAxis]) * scale);
+        bi = bi < 0 ? 0 : (bi >= NB ? NB - 1 : bi);
+        return bi <= bestBin;
+      });
+      mid = (uint32_t)(it - order.begin());
+      if (mid == first || mid > last)
+        mid = first + cnt / 2;
+    }
+    const uint32_t l = build(first, mid - 1, depth + 1);
+    const uint32_t r = build(mid, last, depth + 1);
+    right[me] = r;
+    float *nd = &nodes[8 * (size_t)me];
+    std::memcpy(nd, lo, 12);
+    std::memcpy(nd + 3, &l, 4);
+    std::memcpy(nd + 4, hi, 12);
+    return me;
+  }
+};
+} // namespace
+
 void host_build_bvh(const HostGeometry &g, Bvh &bvh) {
   const uint32_t n = g.numPrims;
   bvh.nodes.clear();
@@ -515,6 +634,28 @@ void host_build_bvh(const HostGeometry &g, Bvh &bvh) {
       box[i + k] -= pad;
       box[i + 3 + k] += pad;
     }
+  if (const char *hb = std::getenv("VR_HOST_BUILD"); hb && std::atoi(hb) == 2) { // binned-SAH tree (experiment)
+    bvh.order.resize(n);
+    std::iota(bvh.order.begin(), bvh.order.end(), 0u);
+    bvh.nodes.reserve((size_t)n * 8);
+    SahBuilder B{box, bvh.order, bvh.nodes, {}, (uint32_t)(g.geo == 0 ? VR_LEAF_MAX : 3), 0, 0};
+    B.right.reserve(n);
+    B.build(0, n - 1, 0);
+    bvh.numNodes = (uint32_t)(bvh.nodes.size() / 8);
+    bvh.numLeaves = B.leaves;
+    bvh.maxDepth = B.maxDepth;
+    std::vector<uint32_t> esc(bvh.numNodes, VR_END);
+    for (uint32_t i = 0; i < bvh.numNodes; ++i) {
+      uint32_t link;
+      std::memcpy(&link, &bvh.nodes[8 * (size_t)i + 3], 4);
+      if (!(link & VR_LEAF)) {
+        esc[link] = B.right[i];
+        esc[B.right[i]] = esc[i];
+      }
+      std::memcpy(&bvh.nodes[8 * (size_t)i + 7], &esc[i], 4);
+    }
+    return;
+  }
   // Morton codes of the box centres
   std::vector<uint64_t> code(n);
   float inv[3]; // (cells in the scene box's proportions, at most VR_MORTON_ANISO : 1 — as morton_kernel, vr_setup.hip)

@@ -957,13 +957,20 @@ trace_kernel(const TraceParams p) {
       hit_clear(hb);
       unsigned nb = fin ? 0u : VR_END;
       bvh_walk_lanes<GEO>(p, fin, org, dir, tnear, hb, nb, 1u VR_DIAG_PASS);
-      if (fin && (hb.geom != h.geom || (hb.geom == 1 && (hb.t != h.t || hb.pos != h.pos)))) {
+      // (the CLOSEST HIT is what is compared — geometry and walls: a packet query leaves a ray that meets a side wall before
+      //  it can enter the scene box without a geometry hit, and the wall wins either way)
+      HitRec hc = h;
+      if (fin) {
+        hit_walls(p, wallS, org, dir, tnear, hb);
+        hit_walls(p, wallS, org, dir, tnear, hc);
+      }
+      if (fin && (hb.geom != hc.geom || hb.t != hc.t || (hb.geom == 1 && hb.pos != hc.pos) || (hb.geom == 0 && hb.prim != hc.prim))) {
         if (atomicAdd(&p.counters[48], 1ull) == 0ull) {
-          const float v[8] = {org.x, org.y, org.z, dir.x, dir.y, dir.z, h.t, hb.t};
+          const float v[8] = {org.x, org.y, org.z, dir.x, dir.y, dir.z, hc.t, hb.t};
           for (int k = 0; k < 8; ++k)
             p.counters[50 + k] = (unsigned long long)__float_as_uint(v[k]);
-          p.counters[58] = ((unsigned long long)h.pos << 32) | hb.pos;
-          p.counters[59] = ((unsigned long long)(unsigned)h.geom << 32) | (unsigned)hb.geom;
+          p.counters[58] = ((unsigned long long)hc.pos << 32) | hb.pos;
+          p.counters[59] = ((unsigned long long)(unsigned)hc.geom << 32) | (unsigned)hb.geom;
         }
       }
     }
