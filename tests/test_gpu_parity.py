@@ -716,6 +716,7 @@ RELIEF_KNOBS = [
     {"VR_NO_SPILL": "1"}, {"VR_DEBUG_FLAGS": "8192"},  # continuing rays stay in the tight general kernel (no spill queue)
     {"VR_LOOSE_BLOCKS": "1"},
     {"VR_PQ_MARGIN": "0"}, {"VR_PQ_MARGIN": "5"},  # packet query without / with a far-reaching frontier cache
+    {"VR_RELIEF_STEPS": "1"}, {"VR_RELIEF_STEPS": "1000"},  # rays whose stretch through the scene box spans > n tiles are loose / never
 ]
 
 

@@ -1471,6 +1471,14 @@ static int prepare_one(vr_context *c) {
     p.rcNx = c->rf.cnx;
     p.rcNy = c->rf.cny;
     p.reliefTravel = travel * c->geo.gridDelta;
+    {
+      // the tile walk of relief_clip starts where the ray enters the SCENE box: a ray that would cross more than `steps`
+      // tiles on its way through it is filed as loose too
+      float steps = 6.f;
+      if (const char *e = std::getenv("VR_RELIEF_STEPS"))
+        steps = std::max(1.f, (float)std::atof(e));
+      p.reliefTanMax = thickScene > 0.f ? steps * c->rf.tile / thickScene : 3.0e38f;
+    }
     p.reliefLookups = 1; // (2: tight launch -0.1 ms, generator +0.4 ms per 1e8 rays — a random 8-byte gather per ray is a 128-byte line from L2)
     if (const char *e = std::getenv("VR_RELIEF_LOOKUPS"))
       p.reliefLookups = std::min(2, std::max(0, std::atoi(e)));

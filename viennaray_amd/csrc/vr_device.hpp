@@ -479,7 +479,9 @@ __device__ __forceinline__ void hit_walls_lds(const TraceParams &p, const float 
 // coordinate, three orders above the rounding of a position) makes that tile's range hold the primitive as well.
 // After VR_RELIEF_STEPS tiles (a grazing ray that the generator did not file apart) the rest of the stretch is kept whole.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, bool on, const V3 &o, const V3 &d, float t0, float t1,
+// Returns true for a lane whose walk was cut short after STEPS tiles (the rest of its stretch is then kept whole).
+template <int STEPS = VR_RELIEF_STEPS>
+__device__ __forceinline__ bool relief_clip(const float *__restrict__ wallS, bool on, const V3 &o, const V3 &d, float t0, float t1,
                                             float &tA, float &tB) {
   typedef float F2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(1))) F2 *GlobalF2;
@@ -503,7 +505,7 @@ __device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, boo
   const float dtx = T * fabsf(inv1), dty = T * fabsf(inv2);
   const float invz = dz != 0.f ? 1.0f / dz : 0.f;
   float tc = t0;
-  bool go = on && t0 <= t1;
+  bool go = on && t0 <= t1, cut = false;
   for (int s = 0; ballot64(go); ++s) {
     if (go) {
       const float tn = fminf(fminf(tx, ty), t1);
@@ -523,10 +525,11 @@ __device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, boo
       }
       if (!(tn < t1)) {
         go = false;
-      } else if (s == VR_RELIEF_STEPS - 1) { // (too many tiles: the rest of the stretch as it is)
+      } else if (s == STEPS - 1) { // (too many tiles: the rest of the stretch as it is)
         tA = fminf(tA, tn);
         tB = t1;
         go = false;
+        cut = true;
       } else {
         if (tx <= ty) {
           ix += sx;
@@ -540,6 +543,7 @@ __device__ __forceinline__ void relief_clip(const float *__restrict__ wallS, boo
       }
     }
   }
+  return cut;
 }
 
 __device__ __forceinline__ V3 safe_inverse(const V3 &d) {

@@ -163,7 +163,7 @@ template <int D> __device__ __forceinline__ unsigned bin_of_relief(const TracePa
   }
   const float u1 = fold_unit((__builtin_fmaf(d1, t, o1) - p.lo1) * p.invExt1, p.bc0);
   const float sin2 = fmaxf(0.f, 1.f - dr * dr);
-  const bool loose = thick * thick * sin2 > p.reliefTravel * p.reliefTravel * (drs * drs);
+  const bool loose = thick * thick * sin2 > p.reliefTravel * p.reliefTravel * (drs * drs) || sin2 > p.reliefTanMax * p.reliefTanMax * (drs * drs);
   const int T1 = loose ? p.looseT1 : p.binT1, T2 = loose ? p.looseT2 : p.binT2, tiles = loose ? p.looseTiles : p.binTiles;
   int c1 = (int)(u1 * (float)T1);
   c1 = c1 < 0 ? 0 : (c1 >= T1 ? T1 - 1 : c1);
@@ -480,6 +480,41 @@ __device__ __forceinline__ void process_boundary_hit(const TraceParams &p, const
   } else { // IGNORE
     active = false;
   }
+}
+
+// "Segments that rise clear" (trace_kernel): does the height field over the source plane (HeightFieldParams, the launch
+// frame's VR_F_HF_*) say that a ray starting at `org` cannot meet the geometry?  It is above its tile's height — the highest
+// point of anything in the tile or its eight neighbours — from tnear on, and rises above the whole scene before it has
+// travelled a tile sideways.  One look-up, no loop.
+template <int D>
+__device__ __forceinline__ bool rises_clear(const float *__restrict__ wallS, const V3 &org, const V3 &dir, float tnear) {
+  const int hnx = __float_as_int(wallS[VR_F_HF_NX]);
+  if (hnx <= 0)
+    return false;
+  const int ax = __float_as_int(wallS[VR_F_RAYDIR]), a1 = __float_as_int(wallS[VR_F_FIRSTDIR]), a2 = __float_as_int(wallS[VR_F_SECONDDIR]);
+  const float sgn = wallS[VR_F_HF_SIGN];
+  const float up = sgn * getc(dir, ax);
+  if (!(up > 0.f))
+    return false;
+  const float hz = sgn * getc(org, ax);
+  const float invT = wallS[VR_F_HF_INVT];
+  const int hny = __float_as_int(wallS[VR_F_HF_NY]);
+  int ix = (int)floorf((getc(org, a1) - wallS[VR_F_HF_LO1]) * invT);
+  ix = ix < 0 ? 0 : (ix >= hnx ? hnx - 1 : ix);
+  int iy = 0;
+  float d2 = 0.f;
+  if (D == 3) {
+    iy = (int)floorf((getc(org, a2) - wallS[VR_F_HF_LO2]) * invT);
+    iy = iy < 0 ? 0 : (iy >= hny ? hny - 1 : iy);
+    d2 = getc(dir, a2);
+  }
+  typedef const __attribute__((address_space(1))) float *GlobalF;
+  const GlobalF field = reinterpret_cast<GlobalF>(((unsigned long long)__float_as_uint(wallS[VR_F_HF_PTR_HI]) << 32) |
+                                                  __float_as_uint(wallS[VR_F_HF_PTR_LO]));
+  const float height = field[iy * hnx + ix];
+  const float d1 = getc(dir, a1);
+  const float tTop = fmaxf(wallS[VR_F_HF_TOP] - hz, 0.f) / up; // where the ray passes the top of the scene box
+  return hz + up * tnear > height && tTop * sqrtf(d1 * d1 + d2 * d2) <= 0.99f * wallS[VR_F_HF_TILE];
 }
 
 // ---------------------------------------------------------------------------
@@ -1350,14 +1385,21 @@ trace_kernel(const TraceParams p) {
           const float tOut = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1));
           reaches = tIn <= tOut; // (as pq_hit_packet's `valid`: otherwise no part of the segment is inside the scene box)
           float tBeg = tQ, tEnd = tOut;
+          bool capped = false;
           if (RELIEF && !(p.debugFlags & 512u)) {
-            // (as the query's own rays: the stretch through the local relief; none — the ray has risen clear of it —
-            //  and the segment cannot meet the geometry)
-            float tA, tB;
-            relief_clip(wallS, reaches, org, dir, tQ, tOut, tA, tB);
-            reaches = reaches && tA <= tB;
-            tBeg = tA;
-            tEnd = tB;
+            // (a reflected ray mostly rises clear of everything near by: the height field's one look-up says so without a
+            //  walk.  Otherwise, as the query's own rays: the stretch through the local relief — none: the ray cannot meet
+            //  the geometry — by a SHORT walk: a grazing ray that is not through after six tiles is left to the next round,
+            //  i.e. to the spill queue; the lanes of a wave walk together, and one such ray kept all of them waiting)
+            if (reaches && rises_clear<D>(wallS, org, dir, tnear)) {
+              reaches = false;
+            } else {
+              float tA, tB;
+              capped = relief_clip<6>(wallS, reaches, org, dir, tQ, tOut, tA, tB);
+              reaches = reaches && tA <= tB;
+              tBeg = tA;
+              tEnd = tB;
+            }
           }
           const float ax = org.x + dir.x * tBeg, ay = org.y + dir.y * tBeg, az = org.z + dir.z * tBeg;
           const float bx = org.x + dir.x * tEnd, by = org.y + dir.y * tEnd, bz = org.z + dir.z * tEnd;
@@ -1365,8 +1407,8 @@ trace_kernel(const TraceParams p) {
           const float pad = p.pqPad;
           const float lx = __uint_as_float(ql.x) + pad, ly = __uint_as_float(ql.y) + pad, lz = __uint_as_float(ql.z) + pad;
           const float hx = __uint_as_float(qh.x) - pad, hy = __uint_as_float(qh.y) - pad, hz = __uint_as_float(qh.z) - pad;
-          inside = !reaches || (fminf(ax, bx) >= lx && fmaxf(ax, bx) <= hx && fminf(ay, by) >= ly && fmaxf(ay, by) <= hy &&
-                                fminf(az, bz) >= lz && fmaxf(az, bz) <= hz);
+          inside = !capped && (!reaches || (fminf(ax, bx) >= lx && fmaxf(ax, bx) <= hx && fminf(ay, by) >= ly && fmaxf(ay, by) <= hy &&
+                                            fminf(az, bz) >= lz && fmaxf(az, bz) <= hz));
           if (RELIEF && (p.debugFlags & 2048u) && !inside) { // EXPERIMENT (wrong results): long continuing rays vanish
             const float ex = bx - ax, ey = by - ay, ez = bz - az;
             if ((ex * ex + ey * ey) + ez * ez > p.reliefTravel * p.reliefTravel)
@@ -1448,34 +1490,7 @@ trace_kernel(const TraceParams p) {
       // (rayTraceKernel.hpp:169-214), and its lane pulls a new ray in the next round.  (Not with a mean free path: that
       // scatter is drawn before the boundary branch.  VR_DEBUG_FLAGS=256 switches this off; the tests run both ways.)
       if (!(p.debugFlags & 256u) && !(EXT && EXT_FULL && p.meanFreePath > 0.f)) {
-        bool clear = false;
-        const int hnx = __float_as_int(wallS[VR_F_HF_NX]);
-        if (hnx > 0 && fin && active) {
-          const int ax = __float_as_int(wallS[VR_F_RAYDIR]), a1 = __float_as_int(wallS[VR_F_FIRSTDIR]), a2 = __float_as_int(wallS[VR_F_SECONDDIR]);
-          const float sgn = wallS[VR_F_HF_SIGN];
-          const float up = sgn * getc(dir, ax);
-          if (up > 0.f) {
-            const float hz = sgn * getc(org, ax);
-            const float invT = wallS[VR_F_HF_INVT];
-            const int hny = __float_as_int(wallS[VR_F_HF_NY]);
-            int ix = (int)floorf((getc(org, a1) - wallS[VR_F_HF_LO1]) * invT);
-            ix = ix < 0 ? 0 : (ix >= hnx ? hnx - 1 : ix);
-            int iy = 0;
-            float d2 = 0.f;
-            if (D == 3) {
-              iy = (int)floorf((getc(org, a2) - wallS[VR_F_HF_LO2]) * invT);
-              iy = iy < 0 ? 0 : (iy >= hny ? hny - 1 : iy);
-              d2 = getc(dir, a2);
-            }
-            typedef const __attribute__((address_space(1))) float *GlobalF;
-            const GlobalF field = reinterpret_cast<GlobalF>(((unsigned long long)__float_as_uint(wallS[VR_F_HF_PTR_HI]) << 32) |
-                                                            __float_as_uint(wallS[VR_F_HF_PTR_LO]));
-            const float height = field[iy * hnx + ix];
-            const float d1 = getc(dir, a1);
-            const float tTop = fmaxf(wallS[VR_F_HF_TOP] - hz, 0.f) / up; // where the ray passes the top of the scene box
-            clear = hz + up * tnear > height && tTop * sqrtf(d1 * d1 + d2 * d2) <= 0.99f * wallS[VR_F_HF_TILE];
-          }
-        }
+        const bool clear = fin && active && rises_clear<D>(wallS, org, dir, tnear);
         if (clear) {
           HitRec h2;
           hit_clear(h2);

@@ -169,6 +169,8 @@ struct TraceParams {
   // then hold fresh, sorted primary rays only, whose packet queries stay small.
   float *spillRec;                 // [batchCount] x 16 floats, or nullptr
   uint32_t *spillCount;            // [1] records written (wave-aggregated cursor)
+  float reliefTanMax;              // ... and when tan(theta) exceeds this: its stretch through the SCENE box would span more tiles
+                                   // than relief_clip should walk (a plane with one bump: thin tiles everywhere, a thick scene box)
   float pqMargin;                  // flat-scene kernels: a packet query searches the 64-ary tree with its box enlarged by this
                                    // much, and the frontier it finds serves the following rounds whose boxes lie inside (0: off)
 };
