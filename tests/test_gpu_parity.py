@@ -841,6 +841,44 @@ def test_relief_packets_with_a_particle_list():
     assert plane == t.numData()
 
 
+def test_relief_packets_as_ray_range_shards():
+    """A scene with relief traced as three shards of the ray-index range through the multi-GPU driver (bound torch
+    accumulators, world size 3: the overflow check's head-room) — tight bins, loose bins and the spill queue of every
+    shard — sums to the plain apply() bit for bit, counters included."""
+    import torch
+    from viennaray_amd import distributed as vd
+    pts, nrm, gd = _relief_surface("ripple", n=130)
+    for sticking in (1.0, 0.15):
+        def mk():
+            t = vr.TraceDisk(3)
+            t.setGeometry(pts, nrm, gd)
+            t.setBoundaryConditions([BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY, BC.REFLECTIVE_BOUNDARY])
+            t.setParticleType(vr.DiffuseParticle(sticking, "flux"))
+            t.setNumberOfRaysFixed(700001)
+            t.setRngSeed(9)
+            return t
+
+        t = mk()
+        t.apply()
+        assert t.traceMode() in (5, 6)
+        ref = t.getFluxF64()
+        t2 = mk()
+        shard = vd.GpuShard(t2, "cuda:0")
+        total = torch.zeros(len(pts), dtype=torch.int64, device="cuda:0")
+        cnt = None
+        for r in range(3):
+            first, count = vd.ray_shard(700001, r, 3)
+            acc, c = shard.trace_local(first, count, run_number=1, world=3)
+            torch.cuda.synchronize()
+            total += acc
+            c = np.asarray(c, dtype=np.int64)
+            cnt = c if cnt is None else cnt + c
+        assert (vd.accumulators_to_flux(total) == ref).all()
+        gi = info_dict(t)
+        for k, v in zip(vd.COUNTER_KEYS, cnt.tolist()):
+            assert gi[k] == v, k
+
+
 def test_relief_is_for_thin_scenes_only():
     """A trench is not "flat with relief": its scene box is sixty cells deep — the general kernels as before."""
     gd, p, n = trench3d()
