@@ -2255,6 +2255,11 @@ int vr_apply_finish(vr_context *c) {
       std::fprintf(stderr, "[vr] trace launch %zu: %.3f ms\n", b, m);
   }
   i.timeTraceKernel = kms * 1e-3;
+  if (std::getenv("VR_PRINT_LAUNCHES") && c->params.spillCount) { // (diagnostics: rays the tight general relief kernel handed over)
+    uint32_t sp = 0;
+    if (hipMemcpy(&sp, c->params.spillCount, 4, hipMemcpyDeviceToHost) == hipSuccess)
+      std::fprintf(stderr, "[vr] spilled rays (last batch): %u\n", sp);
+  }
   double gms = 0.0;
   for (size_t b = 0; b < c->numGenLaunches; ++b) {
     float m = 0.f;

@@ -504,6 +504,9 @@ __device__ __forceinline__ bool relief_clip(const float *__restrict__ wallS, boo
   float ty = d2 != 0.f ? (lo2 + (float)(iy + (d2 > 0.f ? 1 : 0)) * T - o2) * inv2 : big;
   const float dtx = T * fabsf(inv1), dty = T * fabsf(inv2);
   const float invz = dz != 0.f ? 1.0f / dz : 0.f;
+  // (Skipping the air above the relief first — down to the height field's 3 x 3-tile maximum, one look-up — was built and
+  //  measured in round 4: +- 0 on a plane with a bump and on the rippled sheet, the walk being at most six tiles anyway;
+  //  started BELOW a tile's top it also made the query's box too low for the follow-up segments.  Removed.)
   float tc = t0;
   bool go = on && t0 <= t1, cut = false;
   for (int s = 0; ballot64(go); ++s) {
