@@ -1546,7 +1546,8 @@ static int prepare_one(vr_context *c) {
       size_loose(D, q);
       slots = (size_t)q.looseSlotBase + (size_t)q.looseNumBins * binCap + cap;
       cntWords = (size_t)q.looseCntBase + q.looseNumBins + 1;
-      if (slots >= (1ull << 32))
+      // (the loose launch numbers its slots from looseSlotBase on, and bit 31 of such a number marks a spill-queue record)
+      if (slots >= (1ull << 32) || (size_t)q.looseNumBins * binCap + cap >= (1ull << 31))
         return fail(c, VR_E_STATE, "ray stream too large for 32-bit record slots (relief bins)");
     }
     c->slotStride = slots;
