@@ -892,6 +892,34 @@ def test_relief_is_for_thin_scenes_only():
         assert t.traceMode() == mode
 
 
+def test_relief_state_follows_geometry_and_particle_changes():
+    """ONE tracer through a sequence of scenes and particles — rippled sheet (absorbing, then reflecting), the flat plane,
+    a trench, a smaller rippled sheet, the first one again: the relief field, the loose bins, the spill queue and the
+    launch frames are rebuilt or dropped with the scene; every apply equals a fresh oracle's."""
+    gd_t, p_t, n_t = trench3d()
+    r1 = _relief_surface("ripple", n=120)
+    r2 = _relief_surface("steps", n=70, gd=1.0)
+    flat_p, flat_n = vr.io.plane_grid(90, 0.5)
+    seq = [(r1, ("diffuse", 1.0, 1.0), 5), (r1, ("diffuse", 0.15, 1.0), 6), ((flat_p, flat_n, 0.5), ("diffuse", 0.15, 1.0), 3),
+           ((p_t, n_t, gd_t), ("diffuse", 0.3, 1.0), 0), (r2, ("specular", 0.2, 20.0), 6), (r1, ("diffuse", 1.0, 1.0), 5),
+           ((flat_p, flat_n, 0.5), ("diffuse", 1.0, 1.0), 1)]
+    t = vr.TraceDisk(3)
+    bcs = [BC.REFLECTIVE_BOUNDARY, BC.PERIODIC_BOUNDARY, BC.REFLECTIVE_BOUNDARY]
+    t.setBoundaryConditions(bcs)
+    t.setSourceDirection(TD.POS_Z)
+    for run, ((pts, nrm, gd), particle, mode) in enumerate(seq):
+        t.setGeometry(pts, nrm, gd)
+        kind, sticking, power = particle
+        t.setParticleType(vr.DiffuseParticle(sticking, "flux") if kind == "diffuse" else vr.SpecularParticle(sticking, power, "flux"))
+        t.setNumberOfRaysPerPoint(12)
+        t.setRngSeed(99)
+        t.setRunNumber(1)  # (a fresh tracer's: every apply() moves it on, rayTraceDisk.hpp:54)
+        _, o = make_pair_disks(pts, nrm, gd, 3, bcs, TD.POS_Z, particle, rays_pp=12, seed=99)
+        print("scene", run, particle, flush=True)
+        compare(t, o, exact_flux=sticking >= 1.0)
+        assert t.traceMode() == mode, (run, t.traceMode(), mode)
+
+
 @pytest.mark.parametrize("direction", [TD.POS_Z, TD.NEG_Z])
 @pytest.mark.parametrize("particle", [("diffuse", 0.2, 1.0), ("specular", 0.3, 1.0)])
 def test_segments_that_rise_clear_respect_nearby_relief(particle, direction, monkeypatch):
