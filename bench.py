@@ -48,6 +48,10 @@ VALU_PEAK = SIMDS * CLOCK_HZ / 2.0
 SALU_PEAK = CUS * CLOCK_HZ
 
 
+VL1_HIT_LOADS_PER_CLOCK = 1.1  # scattered 16-byte loads per CU-clock served from the vector L1 (tools/gather_rate.hip)
+VL1_MISS_CLOCKS = 2.0          # CU-clocks per load whose 128-byte line comes from the L2
+
+
 def algorithmic_bytes(n_prims, geo_hits, segments, k_neigh=8, h_credit=2.356):
     """bytes a perfect one-ray-at-a-time kernel must move per trace segment.
     hit segment : ceil(log2 N)*32 + (1+K)*28 + (K*4+8) + H*8
@@ -618,6 +622,19 @@ def kernel_block(k, ms, segments=None):
             out[key] = round(k[key], nd)
     if k.get("SQ_WAIT_ANY_frac") is not None:
         out["wait_frac"] = round(k["SQ_WAIT_ANY_frac"], 4)
+    # The roof the WALKING kernels do run under: scattered per-lane loads through the CU's vector L1.  Measured
+    # (tools/gather_rate.hip, profiles/r04_gather_rate.txt; clock read in-kernel): per CU-clock a CU serves 0.83 16-byte
+    # loads when every lane reads its own line from the L1, 1.10 for the two halves of a 32-byte record (pair nodes, disk
+    # records), 1.65 8- or 4-byte loads — and 0.43-0.64 when the 128-byte line comes from the L2 (64 B/clk).  Chip-wide
+    # 500-670 G lane-loads/s from the L1s, 265-390 from the L2s: trench3D's general kernel issues 498 G/s.
+    acc, miss, ghz = k.get("TCP_TOTAL_CACHE_ACCESSES_sum"), k.get("l1_miss_per_access"), k.get("clock_ghz")
+    if acc and miss is not None and ghz:
+        rate = acc / (t * CUS * ghz * 1e9)
+        ceil = 1.0 / ((1.0 - miss) / VL1_HIT_LOADS_PER_CLOCK + miss * VL1_MISS_CLOCKS)
+        out["vector_l1"] = {"lane_loads_per_launch": int(acc), "per_cu_clock": round(rate, 3),
+                            "ceiling_of_this_hit_miss_mix": round(ceil, 3), "frac": round(rate / ceil, 3),
+                            "lane_loads_per_segment": round(acc / segments, 1) if segments else None,
+                            "from": "profiles/r04_gather_rate.txt: ~1.1 loads per CU-clock from the L1 (32-byte records), ~2 clocks per load that misses it"}
     if all(c in k for c in ISSUE_CLASSES):
         total = sum(k[c] for c in ISSUE_CLASSES)
         if segments:
@@ -641,9 +658,16 @@ def roofline(sha, case, trace_ms, gen_ms, segments, rays):
         roof["note"] = "no committed PMC profile of this build and workload: counters are not combined with this run's timing"
         return roof
     roof.update(kernel_block(c["trace_kernel"], trace_ms, segments))
-    roof["limiter"] = ("not HBM: the scene (BVH + records, MBs) is served from the L2s and the Infinity Cache, the ray records "
-                       "stream once; time goes to instruction issue on partly filled wavefronts and to exposed latency "
-                       "(useful_lane_frac, wave_instr_per_segment, wait_frac)")
+    vl1 = (roof.get("vector_l1") or {}).get("frac")
+    if vl1 is not None and vl1 >= 0.7:
+        roof["limiter"] = ("the CU's vector L1 path: the per-lane walks issue scattered 16-byte loads (pair nodes, primitive and "
+                           "neighbour records) at vector_l1.frac of the rate a CU can serve for this hit / miss mix — not HBM "
+                           "(the scene is served from the L2s), not instruction issue")
+    else:
+        roof["limiter"] = ("not HBM: the scene (BVH + records, MBs) is served from the L2s and the Infinity Cache, the ray records "
+                           "stream once; time goes to instruction issue on partly filled wavefronts and to exposed latency "
+                           "(useful_lane_frac, wave_instr_per_segment, wait_frac); vector_l1 says how far the scattered loads "
+                           "are from their own ceiling")
     roof["infinity_cache"] = ("rocprofv3 exposes no MALL hit counter on gfx950 (profiles/r03_rocprof_avail.txt); FETCH_SIZE counts "
                               "L2 misses whether the Infinity Cache or HBM serves them, so frac is an upper bound of the HBM share")
     if gen_ms > 0 and c.get("gen_kernel"):

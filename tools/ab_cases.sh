@@ -1,7 +1,10 @@
-#!/bin/bash
-# Same-box comparison of several builds of the library on case_bench.py workloads, alternating.
-# usage (on the GPU box): LIBS="libviennaray_amd.so libviennaray_amd_o6.so" bash tools/ab_cases.sh "ripple1000a1 0.1 30 2" "ripple1000a3 0.1 30 2" ...
-cd ${GRAFT_REPO_ROOT:-/root/repo}
-for c in "$@"; do for rep in 1 2; do for lib in $LIBS; do
-  echo "$c [$lib] $(VR_LIB_PATH=$PWD/viennaray_amd/$lib python3 tools/case_bench.py $c 2>/dev/null | tail -2 | head -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('mode', d['mode'], 'segments', d['segments'], 'device %.2f trace %.2f ms' % (d['device_ms'], d['trace_kernel_ms']))")"
-done; done; done
+# A/B of library variants (tools/build_variant.sh) on cases of tools/case_bench.py, all in one call (boxes differ by +-8 %):
+#   bash tools/ab_cases.sh "<tag> <tag> ..." "<case args>" ["<case args>" ...]      tag "prod" = the production library
+cd $GRAFT_REPO_ROOT
+tags=$1; shift
+for c in "$@"; do
+  for t in $tags; do
+    lib=$GRAFT_REPO_ROOT/viennaray_amd/libviennaray_amd_$t.so; [ $t = prod ] && lib=$GRAFT_REPO_ROOT/viennaray_amd/libviennaray_amd.so
+    echo -n "$t | "; VR_LIB_PATH=$lib timeout -k 10 200 python3 tools/case_bench.py $c 2>&1 | grep -E "Mrays" | tail -1
+  done
+done
