@@ -277,7 +277,8 @@ def secondary_case(name, rays, sample, threads, sticking=None, reps=2, ray_range
         if r.get("frac") is not None:
             out["roofline"] = {k: r[k] for k in ("kernel", "kernel_ms", "profiled_kernel_ms", "bound", "achieved", "peak", "unit",
                                                  "frac", "traffic", "l2_hit_rate", "useful_lane_frac", "lanes_per_valu_instr",
-                                                 "wave_instr_per_segment", "wait_frac") if k in r}
+                                                 "wave_instr_per_segment", "wait_frac", "l1_miss_per_access", "vector_l1",
+                                                 "limiter") if k in r}
     if sample:
         first = ray_range[0] if ray_range else 0
         out.update(parity_sample(t, mk_oracle, total, min(sample, rays), threads, first))
