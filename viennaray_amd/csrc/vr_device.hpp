@@ -17,7 +17,15 @@ struct V3 {
 };
 
 __device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
-__device__ __forceinline__ float getc(const V3 &v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+// (the three components as VALUES before the choice: written as a choice between v.x, v.y and v.z the compiler selects an
+//  ADDRESS and loads through it — a vector whose component is picked by a run-time axis (rises_clear, relief_clip) then
+//  lives in scratch memory for the whole kernel: the general kernels kept the ray direction there, three scratch loads at
+//  every use.  Round 4, found by reading the ISA for scratch_ after the vector L1 turned out to be the bound: C4 -7 %,
+//  C2 sticking 0.1 -5 %, the headline -3 %, C5 -3 %, trench3D +- 0)
+__device__ __forceinline__ float getc(const V3 &v, int a) {
+  const float x = v.x, y = v.y, z = v.z;
+  return a == 0 ? x : (a == 1 ? y : z);
+}
 __device__ __forceinline__ void setc(V3 &v, int a, float f) {
   v.x = a == 0 ? f : v.x;
   v.y = a == 1 ? f : v.y;
