@@ -1235,8 +1235,12 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
       bool meet = false;
       unsigned f0 = 0, c0 = 0;
       if (lane < nC) {
+        // (the six values FIRST, then one combined test: as a chain of && over volatile reads the ISA was six nested
+        //  branches, each re-loading the spilled LDS address from scratch behind an s_waitcnt vmcnt(0) — six serial trips
+        //  to memory per round of the headline kernel)
         const volatile VR_LDS float *bx = cboxes + 6u * lane;
-        meet = bx[0] <= qhx && bx[3] >= qlx && bx[1] <= qhy && bx[4] >= qly && bx[2] <= qhz && bx[5] >= qlz;
+        const float b0 = bx[0], b1 = bx[1], b2 = bx[2], b3 = bx[3], b4 = bx[4], b5 = bx[5];
+        meet = (b0 <= qhx) & (b3 >= qlx) & (b1 <= qhy) & (b4 >= qly) & (b2 <= qhz) & (b5 >= qlz);
         f0 = lst[lane];
         c0 = lst[64u + lane];
       }
