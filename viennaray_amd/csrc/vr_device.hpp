@@ -68,6 +68,10 @@ typedef unsigned long long u64;
 // wave-wide vote as a lane mask.  (HIP's __ballot compares a materialised 0/1 value:
 // v_cndmask + v_cmp per call; the builtin hands the condition mask through.)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// six comparisons of values already in registers as ONE straight line (a chain of && compiles to nested exec-mask branches)
+__device__ __forceinline__ bool all6(bool a, bool b, bool c, bool d, bool e, bool f) {
+  return ((int)a & (int)b & (int)c & (int)d & (int)e & (int)f) != 0;
+}
 
 // -DVR_DIAG: lane-occupancy counters.  DIAG(k) inside any (divergent) region counts one
 // wave-level execution and the lanes that took part; summed into counters[16 + 2k, +1].
@@ -1141,7 +1145,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
       if (lane < cnt) {
         DIAG(3);
         const float4 a = wide[2 * (size_t)(first + lane)], b = wide[2 * (size_t)(first + lane) + 1];
-        hit = a.x <= qhx && b.x >= qlx && a.y <= qhy && b.y >= qly && a.z <= qhz && b.z >= qlz;
+        hit = all6(a.x <= qhx, b.x >= qlx, a.y <= qhy, b.y >= qly, a.z <= qhz, b.z >= qlz);
         cf = __float_as_uint(a.w);
         cc = __float_as_uint(b.w);
       }
@@ -1189,7 +1193,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
             DIAG(3);
             a = wide[2 * (size_t)(first + lane)];
             b = wide[2 * (size_t)(first + lane) + 1];
-            hit = a.x <= ehx && b.x >= elx && a.y <= ehy && b.y >= ely && a.z <= ehz && b.z >= elz;
+            hit = all6(a.x <= ehx, b.x >= elx, a.y <= ehy, b.y >= ely, a.z <= ehz, b.z >= elz);
             cf = __float_as_uint(a.w);
             cc = __float_as_uint(b.w);
           }
@@ -1273,8 +1277,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
         const unsigned q = first + lane;
         if (GEO == 0) {
           const float4 r0 = prims[2 * (size_t)q];
-          cand = r0.x - r0.w <= qhx && r0.x + r0.w >= qlx && r0.y - r0.w <= qhy && r0.y + r0.w >= qly &&
-                 r0.z - r0.w <= qhz && r0.z + r0.w >= qlz;
+          cand = all6(r0.x - r0.w <= qhx, r0.x + r0.w >= qlx, r0.y - r0.w <= qhy, r0.y + r0.w >= qly, r0.z - r0.w <= qhz, r0.z + r0.w >= qlz);
         } else {
           const float4 r0 = prims[4 * (size_t)q], r1 = prims[4 * (size_t)q + 1], r2 = prims[4 * (size_t)q + 2];
           const float v1x = r0.x - r1.x, v1y = r0.y - r1.y, v1z = r0.z - r1.z;
@@ -1305,8 +1308,7 @@ __device__ __forceinline__ bool pq_hit_packet(const TraceParams &p, bool part, c
         r0 = prims[2 * (size_t)q];
         r1 = prims[2 * (size_t)q + 1];
         // a disc lies inside the ball of its radius
-        cand = r0.x - r0.w <= qhx && r0.x + r0.w >= qlx && r0.y - r0.w <= qhy && r0.y + r0.w >= qly &&
-               r0.z - r0.w <= qhz && r0.z + r0.w >= qlz;
+        cand = all6(r0.x - r0.w <= qhx, r0.x + r0.w >= qlx, r0.y - r0.w <= qhy, r0.y + r0.w >= qly, r0.z - r0.w <= qhz, r0.z + r0.w >= qlz);
       } else {
         r0 = prims[4 * (size_t)q];
         r1 = prims[4 * (size_t)q + 1];
