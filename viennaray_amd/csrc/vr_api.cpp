@@ -1736,7 +1736,8 @@ static int prepare_one(vr_context *c) {
   p.spillRec = nullptr;
   p.spillCount = nullptr;
   if (c->reliefScene && c->looseMode == 7) {
-    VR_HIP(c, c->dSpillRec.ensure_grow((size_t)c->batchCap * 16));
+    // (a record per ray of a batch + the unused end of every wave's last 64-record block)
+    VR_HIP(c, c->dSpillRec.ensure_grow(((size_t)c->batchCap + (size_t)c->grid * (VR_BLOCK / 64) * 64u) * 16));
     VR_HIP(c, c->dSpillCount.ensure(1));
     p.spillRec = c->dSpillRec.p;
     p.spillCount = c->dSpillCount.p;

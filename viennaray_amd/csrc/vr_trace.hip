@@ -563,6 +563,12 @@ __device__ __forceinline__ bool rises_clear(const float *__restrict__ wallS, con
 #define VR_RELIEF_WAVES 8  // waves per SIMD of the absorbing relief kernel (MODE 5)
 #endif
 // MODE 7: MODE 0 that also resumes the rays of MODE 6's spill queue (TraceParams::spillRec) behind its bins
+constexpr unsigned VR_SPILL_BLOCK = 64u; // records of the spill queue a wave reserves at a time (TraceParams::spillRec)
+// the unused records [used, VR_SPILL_BLOCK) of a wave's block marked empty (word 11 = ~0: no ray)
+__device__ __forceinline__ void spill_pad(const TraceParams &p, unsigned base, unsigned used, unsigned lane) {
+  if (used < VR_SPILL_BLOCK && lane >= used)
+    reinterpret_cast<float4 *>(p.spillRec)[4 * (size_t)(base + lane) + 2] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+}
 constexpr int vr_mode_waves(int m) {
   return m == 5 ? VR_RELIEF_WAVES : m == 1 ? 8 : (m == 2 ? 7 : ((m == 3 || m == 6) ? VR_FLAT_WAVES : (m == 4 ? VR_SMALL_WAVES : VR_GENERAL_WAVES)));
 }
@@ -702,6 +708,8 @@ trace_kernel(const TraceParams p) {
   unsigned &initWeightBits = COLD_IN_LDS ? coldS[2 * VR_BLOCK + tid] : initWeightR;
   bool hitFromBack = false;
   bool start = false; // this lane begins a new trace segment in this round
+  // (MODE 6) this wave's block of the spill queue: first record and records used (wave-uniform)
+  unsigned spillBase = 0u, spillUsed = VR_SPILL_BLOCK;
   unsigned node = VR_END; // cursor of the lane's BVH walk (VR_END: none under way)
   unsigned sp = 0u;       // ... and the depth of its stack
   unsigned *const stackG = p.walkStack + (size_t)gwave * (VR_STACK_GLOBAL * 64u) + lane;
@@ -722,7 +730,10 @@ trace_kernel(const TraceParams p) {
   const unsigned ovChunks = (ovCount + p.binCap - 1) / p.binCap;
   // (MODE 7: the spill queue's records, in chunks of a bin's capacity, are the virtual bins behind the overflow chunks)
   const unsigned spillN = (RESUME && p.spillRec) ? ((ConstU32)p.spillCount)[0] : 0u;
-  const unsigned totalBins = p.numBins + ovChunks + (RESUME ? (spillN + p.binCap - 1) / p.binCap : 0u);
+  // (the queue is made of 64-record blocks, each with a ray in its first record and possibly unused records at its end:
+  //  a chunk of at least a block, block aligned, so that a refill which finds no ray has truly run out of work)
+  const unsigned spillChunk = p.binCap < VR_SPILL_BLOCK ? VR_SPILL_BLOCK : (p.binCap / VR_SPILL_BLOCK) * VR_SPILL_BLOCK;
+  const unsigned totalBins = p.numBins + ovChunks + (RESUME ? (spillN + spillChunk - 1) / spillChunk : 0u);
   unsigned curBin = 0, spanStart = 0, spanEnd = 0, curOff = 0, curCnt = 0, curBase = 0;
   unsigned spanCounts = 0; // lane i: ray count of bin spanStart + i
   // (only the general flat-scene kernel has the queues compiled in — it is the one they pay for, vr_api.cpp — the others
@@ -822,8 +833,8 @@ trace_kernel(const TraceParams p) {
             curCnt = ovCount - k < p.binCap ? ovCount - k : p.binCap;
             curBase = p.numBins * p.binCap + k;
           } else { // a chunk of the spill queue: bit 31 marks its record numbers
-            const unsigned k = (curBin - p.numBins - ovChunks) * p.binCap;
-            curCnt = spillN - k < p.binCap ? spillN - k : p.binCap;
+            const unsigned k = (curBin - p.numBins - ovChunks) * spillChunk;
+            curCnt = spillN - k < spillChunk ? spillN - k : spillChunk;
             curBase = 0x80000000u | k;
           }
           curCnt = __builtin_amdgcn_readfirstlane(curCnt);
@@ -841,6 +852,7 @@ trace_kernel(const TraceParams p) {
         // a ray of the spill queue: its whole state as the relief kernel left it
         const float4 *__restrict__ sr = reinterpret_cast<const float4 *>(p.spillRec) + 4 * (size_t)(slot & 0x7FFFFFFFu);
         const float4 r0 = sr[0], r1 = sr[1], r2 = sr[2], r3 = sr[3];
+        const bool ray = __float_as_uint(r2.w) != 0xFFFFFFFFu; // (the unused end of a wave's block: spill_pad)
         org = mk(r0.x, r0.y, r0.z);
         rayWeight = r0.w;
         rayDirection = mk(r1.x, r1.y, r1.z);
@@ -850,8 +862,8 @@ trace_kernel(const TraceParams p) {
         numReflections = __float_as_uint(r2.y);
         boundaryHits = __float_as_uint(r2.z) & 0x7FFFFFFFu;
         hitFromBack = (__float_as_uint(r2.z) >> 31) != 0u;
-        active = true;
-        start = true;
+        active = ray;
+        start = ray;
         resumed = true;
       }
       if (slot != 0xFFFFFFFFu && !resumed) {
@@ -1460,12 +1472,20 @@ trace_kernel(const TraceParams p) {
         const bool sp = active && start;
         const unsigned long long sm = ballot64(sp);
         if (sm) {
-          unsigned base = 0;
-          if (lane == (unsigned)(__ffsll((long long)sm) - 1))
-            base = atomicAdd(p.spillCount, (unsigned)__popcll(sm));
-          base = (unsigned)__shfl((int)base, __ffsll((long long)sm) - 1, 64);
+          // (the queue in BLOCKS of 64 records, each filled by one wave: the records of a block are rays of one
+          //  neighbourhood — this wave's consecutive rounds — and the resuming kernel takes a block per round; filed in
+          //  order of arrival, 8 rays of a round side by side, its waves held rays of eight places.  Only a wave's last
+          //  block has unused records: spill_pad at the end of the kernel)
+          const unsigned n = (unsigned)__popcll(sm), room = VR_SPILL_BLOCK - spillUsed;
+          unsigned nextBase = 0u;
+          if (n > room) { // (the block is filled up, the rest of the round's rays open the next one)
+            if (lane == 0u)
+              nextBase = atomicAdd(p.spillCount, VR_SPILL_BLOCK);
+            nextBase = (unsigned)__builtin_amdgcn_readfirstlane((int)nextBase);
+          }
           if (sp) {
-            float4 *sr = reinterpret_cast<float4 *>(p.spillRec) + 4 * (size_t)(base + (unsigned)__popcll(sm & ((1ull << lane) - 1ull)));
+            const unsigned rank = (unsigned)__popcll(sm & ((1ull << lane) - 1ull));
+            float4 *sr = reinterpret_cast<float4 *>(p.spillRec) + 4 * (size_t)(rank < room ? spillBase + spillUsed + rank : nextBase + (rank - room));
             sr[0] = make_float4(org.x, org.y, org.z, rayWeight);
             sr[1] = make_float4(rayDirection.x, rayDirection.y, rayDirection.z, __uint_as_float(rng.seed)); // (the engine's seed: tea3(idx, seed))
             sr[2] = make_float4(__uint_as_float(rng.k), __uint_as_float(numReflections),
@@ -1475,6 +1495,8 @@ trace_kernel(const TraceParams p) {
             active = false;
             start = false;
           }
+          spillBase = n > room ? nextBase : spillBase;
+          spillUsed = n > room ? n - room : spillUsed + n;
         }
       }
     }
@@ -1517,6 +1539,10 @@ trace_kernel(const TraceParams p) {
       }
     }
     TICK(6);
+  }
+  if constexpr (FOLLOW && RELIEF) {
+    if (p.spillRec)
+      spill_pad(p, spillBase, spillUsed, lane); // (the unused end of this wave's last block: no rays)
   }
 
   if (SMALL) {
