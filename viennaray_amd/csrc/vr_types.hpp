@@ -163,12 +163,14 @@ struct TraceParams {
   int32_t reliefLookups;           // coarse look-ups of the generator's hit prediction (1 or 2)
   // Spill queue of the general relief kernel (MODE 6): a ray that would go on into the NEXT round — its follow-up segment
   // was not finished inside the round of its packet query — leaves the kernel as a 64-byte full-state record
-  //   {org.xyz, weight} {rayDirection.xyz, bits(idx - batchFirst)} {bits(k), bits(reflections), bits(boundaryHits | back << 31), -}
+  //   {org.xyz, weight} {rayDirection.xyz, bits(seed)} {bits(k), bits(reflections), bits(boundaryHits | back << 31), 0 (~0: no ray)}
   //   {s[k] lo, hi, s[k+156] lo, hi}
+  // in blocks of 64 records (VR_SPILL_BLOCK, vr_trace.hip), one wave per block: a wave reserves a block with ONE atomic
+  // on spillCount and fills it over its next rounds; the unused end of a wave's last block is marked empty
   // and the launch over the loose bins (MODE 7 = MODE 0 + these records) traces it to its end: the tight kernel's waves
   // then hold fresh, sorted primary rays only, whose packet queries stay small.
-  float *spillRec;                 // [batchCount] x 16 floats, or nullptr
-  uint32_t *spillCount;            // [1] records written (wave-aggregated cursor)
+  float *spillRec;                 // [batchCount + 64 per wave] x 16 floats, or nullptr
+  uint32_t *spillCount;            // [1] records reserved: a multiple of 64
   float reliefTanMax;              // ... and when tan(theta) exceeds this: its stretch through the SCENE box would span more tiles
                                    // than relief_clip should walk (a plane with one bump: thin tiles everywhere, a thick scene box)
   float pqMargin;                  // flat-scene kernels: a packet query searches the 64-ary tree with its box enlarged by this
