@@ -20,7 +20,8 @@
   } while (0)
 
 // PATTERN 0: every lane its own random 32-byte slot; 1: the two 16-byte halves of one slot (a pair node);
-// 2: all lanes of a wave the same slot (a coherent wave); 3: lanes in groups of 4 share a slot
+// 2: all lanes of a wave the same slot (a coherent wave); 3: lanes in groups of 4 share a slot;
+// 4: 16 + 8 bytes of one 24-byte slot, five slots per 128-byte line (a 24-byte pair node)
 template <int WIDTH, int PATTERN>
 __global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ table, unsigned slots, unsigned iters,
                                                       unsigned long long *out) {
@@ -36,11 +37,27 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint4 *__restrict__ t
   for (unsigned it = 0; it < iters; ++it) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if (PATTERN != 1 || !(k & 1)) { // (PATTERN 1: the second load is the other half of the same slot)
+      if (PATTERN != 4 && (PATTERN != 1 || !(k & 1))) { // (PATTERN 1: the second load is the other half of the same slot)
         s = s * 1664525u + 1013904223u;
         slot = (s >> 8) & (slots - 1u); // (slots is a power of two)
       }
       const uint4 *p = table + 2u * slot + (PATTERN == 1 ? (k & 1) : 0);
+      if (PATTERN == 4) {
+        if (!(k & 1)) {
+          s = s * 1664525u + 1013904223u;
+          slot = (s >> 8) & (slots - 1u);
+        }
+        const unsigned line = slot / 5u, in = slot - line * 5u; // (slots counts 32-byte units: lines = slots / 4 >= slots / 5)
+        const char *q = reinterpret_cast<const char *>(table) + (size_t)(line & (slots / 4u - 1u)) * 128u + in * 24u;
+        if (k & 1) {
+          const uint2 v = *reinterpret_cast<const uint2 *>(q + 16);
+          acc ^= v.x ^ v.y;
+        } else {
+          const uint4 v = *reinterpret_cast<const uint4 *>(q);
+          acc ^= v.x ^ v.w;
+        }
+        continue;
+      }
       if (WIDTH == 4) {
         const uint4 v = *p;
         acc ^= v.x ^ v.w;
@@ -107,6 +124,8 @@ int main() {
     run<4, 0>("16 B per lane, every lane its own line", 64 << 20, w, cus);
     run<4, 1>("2 x 16 B of one 32-byte slot (a pair node)", 16 << 10, w, cus);
     run<4, 1>("2 x 16 B of one 32-byte slot (a pair node)", 256 << 10, w, cus);
+    run<4, 4>("16 + 8 B of one 24-byte slot, 5 per line", 16 << 10, w, cus);
+    run<4, 4>("16 + 8 B of one 24-byte slot, 5 per line", 256 << 10, w, cus);
     run<2, 0>("8 B per lane, own line", 16 << 10, w, cus);
     run<1, 0>("4 B per lane, own line", 16 << 10, w, cus);
     run<4, 2>("16 B, all lanes of a wave one address", 16 << 10, w, cus);
