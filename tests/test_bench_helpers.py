@@ -43,6 +43,25 @@ def test_roofline_block_is_counter_bytes_over_time_over_peak():
     assert "issue_diag" in r and "frac" not in r["issue_diag"]
 
 
+def test_vector_l1_block_prices_scattered_loads_against_the_measured_ceiling():
+    """roofline.vector_l1: lane-loads per CU-clock = TCP_TOTAL_CACHE_ACCESSES / (time x 256 CUs x clock)
+    against the harmonic mix of ~1.1 loads per clock from the L1 and 2 clocks per L1 miss (tools/gather_rate.hip); the
+    limiter names that path where the fraction is >= 0.7."""
+    b = _bench()
+    k = {"name": "trace_kernel<3,0,0,0>", "avg_ms": 28.0, "TCP_TOTAL_CACHE_ACCESSES_sum": 13.9e9, "l1_miss_per_access": 0.24,
+         "clock_ghz": 2.27}
+    blk = b.kernel_block(k, 28.0, segments=189_000_000)
+    v = blk["vector_l1"]
+    rate = 13.9e9 / (28.0e-3 * 256 * 2.27e9)
+    ceil = 1.0 / (0.76 / b.VL1_HIT_LOADS_PER_CLOCK + 0.24 * b.VL1_MISS_CLOCKS)
+    assert abs(v["per_cu_clock"] - rate) < 1e-3 and abs(v["ceiling_of_this_hit_miss_mix"] - ceil) < 1e-3
+    assert abs(v["frac"] - rate / ceil) < 2e-3 and 0.9 < v["frac"] < 1.1
+    assert abs(v["lane_loads_per_segment"] - 13.9e9 / 189e6) < 0.1
+    # a kernel whose rays share addresses is far from that ceiling
+    k2 = dict(k, TCP_TOTAL_CACHE_ACCESSES_sum=0.9e9, avg_ms=5.5)
+    assert b.kernel_block(k2, 5.5)["vector_l1"]["frac"] < 0.5
+
+
 def test_single_gpu_step_ends_with_the_flux_on_the_host():
     """N = 1: a timed step is the reference's whole apply() — through the float flux in the host's TracingData
     (rayTraceDisk.hpp:40-57, rayTrace.hpp:135) — i.e. `Trace.apply()`, which downloads; N > 1: the shard + all-reduce on
